@@ -1,0 +1,292 @@
+"""Generate the committed golden vectors by running the REFERENCE's own code (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+What is executed from /root/reference (imported in place, never copied; see ref_import.py):
+  G1  src.model.denoiser.mvdream.attention.SpatialTransformer3D.forward
+  G2  src.model.denoiser.mvdream.attention.CrossAttention.forward
+  G3  src.geometry.projection.{sample_image_grid,get_world_rays}, src.misc.camera_utils.absolute_to_relative_camera
+  G4  src.model.denoiser.mvunet.MultiViewUNet.{__init__,forward}  (walking the oracle's diffusers blocks)
+  G5  src.model.diffusion_wrapper.DiffusionWrapper.{step,sample,ray_encode,first_stage_encode,last_stage_decode}
+  G7  src.model.diffusion_wrapper.DiffusionWrapper.{test_video_anchored,test_video_autoregressive} bookkeeping
+      with `sample()` stubbed out (index schedules only)
+G6 (DDIM tables / one step KAT) comes from the oracle's own scheduler: diffusers is absent, so that
+arithmetic is "parity unpinned" by the reference; the fixture pins it against drift.
+
+Weights are regenerated from seeds (seeded.py); inputs and outputs are stored explicitly (float32).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from dataclasses import dataclass
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent.parent))
+sys.dont_write_bytecode = True
+
+import ref_import as R  # noqa: E402
+from seeded import checksum, load_seeded, random_cameras, seeded_state  # noqa: E402
+
+torch.set_num_threads(8)
+torch.set_grad_enabled(False)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"wrote {name}.npz  ({sum(a.nbytes for a in out.values()) / 1e3:.0f} kB raw)")
+
+
+# ----------------------------------------------------------------------------------------------- G1 / G2
+def g1_g2():
+    A = R.ref("src.model.denoiser.mvdream.attention")
+    cases = {}
+    for i, (C, V, h, w, b, seed) in enumerate([(64, 1, 4, 4, 1, 0), (64, 2, 8, 8, 2, 1), (64, 5, 4, 8, 1, 2),
+                                                (320, 2, 4, 4, 1, 3), (320, 5, 8, 8, 1, 4)]):
+        cfg = A.SpatialTransformer3DCfg(name="spatial_transformer_3d", num_heads=8)
+        m = A.SpatialTransformer3D(cfg, C).eval()
+        cs = load_seeded(m, 100 + seed)
+        x = torch.randn(b, V, C, h, w, generator=torch.Generator().manual_seed(seed))
+        y = m(x)
+        cases[f"c{i}_meta"] = np.array([C, V, h, w, b, 100 + seed])
+        cases[f"c{i}_checksum"] = cs
+        cases[f"c{i}_x"], cases[f"c{i}_y"] = x, y
+    cases["n"] = 5
+    save("g1_spatial_transformer_3d", **cases)
+
+    cases = {}
+    for i, (heads, d, L, bsz, seed) in enumerate([(2, 40, 24, 2, 0), (2, 80, 17, 1, 1), (2, 160, 33, 1, 2),
+                                                   (5, 64, 16, 3, 3)]):
+        m = A.CrossAttention(query_dim=heads * d, heads=heads, dim_head=d).eval()
+        cs = load_seeded(m, 200 + seed)
+        x = torch.randn(bsz, L, heads * d, generator=torch.Generator().manual_seed(seed))
+        cases[f"c{i}_meta"] = np.array([heads, d, L, bsz, 200 + seed])
+        cases[f"c{i}_checksum"] = cs
+        cases[f"c{i}_x"], cases[f"c{i}_y"] = x, m(x)
+    cases["n"] = 4
+    save("g2_cross_attention", **cases)
+
+
+# ----------------------------------------------------------------------------------------------- G3
+def g3():
+    P = R.ref("src.geometry.projection")
+    Cm = R.ref("src.misc.camera_utils")
+    from einops import rearrange
+    extr, intr = random_cameras(2, 4, seed=7)
+    # make the first camera non-identity too so that inv() is exercised
+    extr = extr[:, [1, 0, 2, 3]]
+    out = {}
+    for (h, w) in [(8, 8), (4, 6)]:
+        xy, _ = P.sample_image_grid((h, w))
+        o, d = P.get_world_rays(rearrange(xy, "h w xy -> (h w) xy"),
+                                rearrange(extr, "b v i j -> b v () i j"),
+                                rearrange(intr, "b v i j -> b v () i j"))
+        out[f"xy_{h}x{w}"], out[f"origins_{h}x{w}"], out[f"directions_{h}x{w}"] = xy, o, d
+    out["extrinsics"], out["intrinsics"] = extr, intr
+    for idx in (0, 1, 3):
+        out[f"relative_{idx}"] = Cm.absolute_to_relative_camera(extr, idx)
+    save("g3_rays", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G4
+SD_TINY = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4))
+
+
+def _ref_mvunet(topology: str, widths):
+    """Build the REFERENCE MultiViewUNet (its __init__ runs, mvunet.py:43-88)."""
+    R.install()
+    import diffusers
+    M = R.ref("src.model.denoiser.mvunet")
+    A = R.ref("src.model.denoiser.mvdream.attention")
+    mv = A.SpatialTransformer3DCfg(name="spatial_transformer_3d", num_heads=8)
+    if topology == "scratch":
+        ae = M.UNet2DModelCfg(name="unet", down_block_types=["DownBlock2D"] * 4, mid_block_type="UNetMidBlock2D",
+                              up_block_types=["UpBlock2D"] * 4, only_cross_attention=False,
+                              block_out_channels=list(widths))
+        cfg = M.MultiViewUNetCfg(name="mv_unet", autoencoder=ae, multi_view_attention=mv, pretrained_from=None)
+        return M.MultiViewUNet(cfg, 11, 4).eval()
+    ae = M.UNet2DModelCfg(name="unet", down_block_types=[], mid_block_type="", up_block_types=[],
+                          only_cross_attention=False, block_out_channels=list(widths))
+    cfg = M.MultiViewUNetCfg(name="mv_unet", autoencoder=ae, multi_view_attention=mv,
+                             pretrained_from="stabilityai/stable-diffusion-2-1")
+    orig = diffusers.UNet2DConditionModel.from_pretrained
+    over = dict(block_out_channels=tuple(widths), attention_head_dim=tuple(max(1, c // 64) for c in widths))
+    diffusers.UNet2DConditionModel.from_pretrained = classmethod(
+        lambda cls, path, subfolder="unet": orig.__func__(cls, path, subfolder, config_overrides=over))
+    try:
+        return M.MultiViewUNet(cfg, 11, 4).eval()
+    finally:
+        diffusers.UNet2DConditionModel.from_pretrained = orig
+
+
+def g4():
+    out = {}
+    cases = [("scratch", (32, 64, 128, 128), 1, 2, 8, "2d", 0),
+             ("scratch", (32, 64, 128, 128), 1, 3, 16, "1d", 1),
+             ("sd", (64, 128, 256, 256), 1, 2, 8, "2d", 2),
+             ("sd", (64, 128, 256, 256), 2, 3, 8, "2d", 3),
+             ("sd", (64, 128, 256, 256), 1, 1, 64, "2d", 4),   # 64x64: exercises the h<=32 gate
+             ]
+    for i, (topo, widths, b, V, h, tform, seed) in enumerate(cases):
+        m = _ref_mvunet(topo, widths)
+        cs = load_seeded(m, 300 + seed)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(b, V, 11, h, h, generator=g)
+        t = torch.randint(0, 1000, (b, V) if tform == "2d" else (b,), generator=g)
+        if tform == "2d":
+            t[:, 0] = 0
+        with R.cpu_cuda():
+            y = m.forward(x, t)
+        out[f"c{i}_topology"] = topo
+        out[f"c{i}_widths"] = np.array(widths)
+        out[f"c{i}_seed"] = 300 + seed
+        out[f"c{i}_checksum"] = cs
+        out[f"c{i}_nkeys"] = len(m.state_dict())
+        out[f"c{i}_x"], out[f"c{i}_t"], out[f"c{i}_y"] = x, t, y
+        print(f"  g4 case {i}: {topo} {widths} b{b} V{V} h{h} -> |y| {y.abs().mean():.4f}")
+    out["n"] = len(cases)
+    save("g4_mvunet_forward", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G5
+def _ref_wrapper(use_cfg: bool, widths=(64, 128, 256, 256), vae_widths=(32, 64), n_steps=5):
+    """Build the REFERENCE DiffusionWrapper (its __init__ runs, diffusion_wrapper.py:71-150) on the
+    SD-like topology at reduced widths."""
+    R.install()
+    import diffusers
+    W = R.ref("src.model.diffusion_wrapper")
+    M = R.ref("src.model.denoiser.mvunet")
+    A = R.ref("src.model.denoiser.mvdream.attention")
+    S = R.ref("src.model.scheduler")
+    Sd = R.ref("src.model.scheduler.ddim")
+    mv = A.SpatialTransformer3DCfg(name="spatial_transformer_3d", num_heads=8)
+    ae = M.UNet2DModelCfg(name="unet", down_block_types=[], mid_block_type="", up_block_types=[],
+                          only_cross_attention=False, block_out_channels=list(widths))
+    den = M.MultiViewUNetCfg(name="mv_unet", autoencoder=ae, multi_view_attention=mv,
+                             pretrained_from="stabilityai/stable-diffusion-2-1")
+    sched = S.SchedulerCfg(name="ddim", num_train_timesteps=1000, num_inference_steps=n_steps, pretrained_from=None,
+                           kwargs=Sd.DDIMSchedulerCfg(clip_sample=False))
+    vae_cfg = SimpleNamespace(name="kl", pretrained_from="stabilityai/stable-diffusion-2-1",
+                              kwargs=SimpleNamespace(latent_channels=4))
+    model_cfg = SimpleNamespace(denoiser=den, scheduler=sched, autoencoder=vae_cfg,
+                                ray_encodings=SimpleNamespace(num_origin_octaves=15, num_direction_octaves=15),
+                                use_cfg=use_cfg, cfg_scale=3.0, cfg_train=True, use_ray_encoding=False,
+                                srt_ray_encoding=False, use_plucker=False, ema=False, use_ema_sampling=False,
+                                enable_xformers_memory_efficient_attention=False)
+    o_unet = diffusers.UNet2DConditionModel.from_pretrained
+    o_vae = diffusers.AutoencoderKL.from_pretrained
+    over = dict(block_out_channels=tuple(widths), attention_head_dim=tuple(max(1, c // 64) for c in widths))
+    vover = dict(block_out_channels=tuple(vae_widths), layers_per_block=1)
+    diffusers.UNet2DConditionModel.from_pretrained = classmethod(
+        lambda cls, path, subfolder="unet": o_unet.__func__(cls, path, subfolder, config_overrides=over))
+    diffusers.AutoencoderKL.from_pretrained = classmethod(
+        lambda cls, path, subfolder="vae": o_vae.__func__(cls, path, subfolder, config_overrides=vover))
+    try:
+        w = W.DiffusionWrapper(model_cfg, SimpleNamespace(), SimpleNamespace(), SimpleNamespace(),
+                               SimpleNamespace(denoiser=False, autoencoder=True), None, None)
+    finally:
+        diffusers.UNet2DConditionModel.from_pretrained = o_unet
+        diffusers.AutoencoderKL.from_pretrained = o_vae
+    return w.eval()
+
+
+def g5():
+    out = {}
+    for ci, use_cfg in enumerate([False, True]):
+        w = _ref_wrapper(use_cfg)
+        cs_d = load_seeded(w.denoiser, 400)
+        cs_v = load_seeded(w.autoencoder, 401)
+        b, v_c, v_t, H = 1, 1, 2, 32          # VAE widths (32,64): one downsample -> latents 16x16
+        g = torch.Generator().manual_seed(5 + ci)
+        ctx_img = torch.rand(b, v_c, 3, H, H, generator=g)
+        extr, intr = random_cameras(b, v_c + v_t, seed=11 + ci)
+        hl = H // 2
+        enc_noise = torch.randn(b * v_c, 4, hl, hl, generator=g)
+        x_T = torch.randn(b, v_t, 4, hl, hl, generator=g)
+        batch = {"context": {"image": ctx_img, "extrinsics": extr[:, :v_c], "intrinsics": intr[:, :v_c]},
+                 "target": {"image": torch.zeros(b, v_t, 3, H, H), "extrinsics": extr[:, v_c:],
+                            "intrinsics": intr[:, v_c:]},
+                 "scene": ["synthetic"]}
+        w.set_timesteps(5)
+        # the reference draws its noise from the global CPU generator (diffusion_wrapper.py:283,473):
+        # feed it the recorded draws by patching randn for the duration of the call
+        draws = [enc_noise, x_T]
+        o_randn = torch.randn
+        import oracle.vae as ovae
+
+        def fake_randn(*shape, **kw):
+            t = draws.pop(0)
+            shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            assert tuple(t.shape) == shp, (t.shape, shp)
+            return t.clone()
+        torch.randn = fake_randn
+        try:
+            with R.cpu_cuda():
+                img, _ = w.sample(batch)
+        finally:
+            torch.randn = o_randn
+        assert not draws
+        # one isolated step as well (diffusion_wrapper.py:413-453)
+        ctx_lat = torch.randn(b, v_c, 4, hl, hl, generator=g)
+        x_t = torch.randn(b, v_t, 4, hl, hl, generator=g)
+        with R.cpu_cuda():
+            rays = w.ray_encode(batch, ctx_lat, x_t)
+            ctx_in = torch.cat([ctx_lat, torch.zeros(b, v_c, 1, hl, hl)], dim=2)
+            x_prev = w.step(w.denoiser, x_t, w.scheduler.timesteps[1], ctx_in, rays, torch.ones(b, v_t, 1, hl, hl))
+        p = f"c{ci}_"
+        out.update({p + "use_cfg": int(use_cfg), p + "checksum_denoiser": cs_d, p + "checksum_vae": cs_v,
+                    p + "ctx_img": ctx_img, p + "extr": extr, p + "intr": intr, p + "enc_noise": enc_noise,
+                    p + "x_T": x_T, p + "img": img, p + "rays": rays, p + "step_ctx_lat": ctx_lat,
+                    p + "step_x_t": x_t, p + "step_ts": int(w.scheduler.timesteps[1]), p + "step_x_prev": x_prev})
+        print(f"  g5 cfg={use_cfg}: img mean {img.mean():.4f}")
+    out["n"] = 2
+    out["widths"] = np.array([64, 128, 256, 256])
+    out["vae_widths"] = np.array([32, 64])
+    save("g5_step_sample", **out)
+
+
+# ----------------------------------------------------------------------------------------------- G6
+def g6():
+    from oracle.scheduler import DDIMScheduler
+    s = DDIMScheduler(clip_sample=False)
+    out = {"alphas_cumprod": s.alphas_cumprod, "betas": s.betas}
+    for n in (5, 25, 50, 70):
+        s.set_timesteps(n)
+        out[f"timesteps_{n}"] = s.timesteps
+    s.set_timesteps(50)
+    g = torch.Generator().manual_seed(6)
+    x, e = torch.randn(2, 3, 4, 8, 8, generator=g), torch.randn(2, 3, 4, 8, 8, generator=g)
+    out["kat_x"], out["kat_eps"] = x, e
+    for t in (980, 500, 0):
+        out[f"kat_prev_{t}"] = s.step(e, torch.tensor(t), x).prev_sample
+    out["kat_add_noise"] = s.add_noise(x, e, torch.tensor([10, 900]))
+    save("g6_ddim", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7"]
+    if "g1" in which:
+        g1_g2()
+    if "g3" in which:
+        g3()
+    if "g4" in which:
+        g4()
+    if "g5" in which:
+        g5()
+    if "g6" in which:
+        g6()
+    if "g7" in which:
+        from make_golden_schedules import g7
+        g7()
+    assert not list(Path(R.REF_ROOT).rglob("__pycache__")), "reference tree was written to"
