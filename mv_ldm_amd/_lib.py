@@ -1,0 +1,144 @@
+"""ctypes binding of libmvldm_hip.so (the C ABI declared in include/mvldm.h).
+
+The product path has NO CPU fallback: if the shared library is missing or fails to load, importing
+anything that computes raises.  (`load(required=False)` exists only so that CPU-only tooling --
+symbol-export tests, plan building on meta tensors -- can introspect without a GPU.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmvldm_hip.so"
+
+F32, BF16, F16 = 0, 1, 2
+EPI_NONE, EPI_SILU, EPI_GEGLU = 0, 1, 2
+ELT_COPY, ELT_SILU = 0, 1
+GN_MAX_CHUNKS = 32
+
+(OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_TIMESTEP_EMBED, OP_ELTWISE, OP_DDIM_STEP, OP_DDIM_ADVANCE,
+ OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY) = range(1, 12)
+
+vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+
+
+class IgemmDesc(C.Structure):
+    _fields_ = [("src0", vp), ("src1", vp), ("weight", vp), ("bias", vp), ("row_bias", vp), ("residual", vp),
+                ("dst", vp), ("workspace", vp),
+                ("c0", i32), ("c1", i32),
+                ("n_img", i32), ("h_in", i32), ("w_in", i32), ("h_out", i32), ("w_out", i32),
+                ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
+                ("n_out", i32), ("n_pad", i32), ("k_pad", i32),
+                ("row_bias_ld", i32), ("epilogue", i32), ("act_dtype", i32), ("dst_dtype", i32),
+                ("splitk", i32), ("tile", i32), ("out_scale", f32), ("workspace_bytes", sz)]
+
+
+class _GroupNorm(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("stats_ws", vp),
+                ("n_img", i32), ("hw", i32), ("c", i32), ("groups", i32), ("silu", i32), ("dtype", i32), ("eps", f32)]
+
+
+class _LayerNorm(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("rows", i32), ("c", i32), ("dtype", i32), ("eps", f32)]
+
+
+class _Attention(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp), ("seg", vp),
+                ("ld_q", i32), ("ld_k", i32), ("ld_v", i32), ("ld_o", i32), ("heads", i32), ("head_dim", i32),
+                ("n_seg", i32), ("max_q_len", i32), ("dtype", i32), ("scale", f32)]
+
+
+class _Temb(C.Structure):
+    _fields_ = [("timesteps", vp), ("freqs", vp), ("out", vp), ("n", i32), ("dim", i32), ("flip", i32), ("dst_dtype", i32)]
+
+
+class _Eltwise(C.Structure):
+    _fields_ = [("x", vp), ("y", vp), ("n", sz), ("op", i32), ("src_dtype", i32), ("dst_dtype", i32)]
+
+
+class _Ddim(C.Structure):
+    _fields_ = [("eps", vp), ("x_t", vp), ("x_next", vp), ("cond_img", vp), ("uncond_img", vp), ("coef", vp),
+                ("step_ptr", vp), ("unet_in", vp),
+                ("n_tgt", i32), ("hw", i32), ("c", i32), ("unet_in_c", i32), ("unet_in_dtype", i32), ("cfg_scale", f32)]
+
+
+class _Advance(C.Structure):
+    _fields_ = [("step_ptr", vp), ("t_table", vp), ("timesteps", vp), ("tgt_rows", vp), ("n_steps", i32), ("n_rows", i32)]
+
+
+class _Layout(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("n_img", i32), ("c", i32), ("hw", i32), ("other_c", i32),
+                ("other_c_off", i32), ("dtype", i32), ("clamp01", i32), ("scale", f32), ("shift", f32)]
+
+
+class _Memcpy(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("bytes", sz)]
+
+
+class _OpUnion(C.Union):
+    _fields_ = [("igemm", IgemmDesc), ("groupnorm", _GroupNorm), ("layernorm", _LayerNorm), ("attention", _Attention),
+                ("temb", _Temb), ("eltwise", _Eltwise), ("ddim", _Ddim), ("advance", _Advance), ("layout", _Layout),
+                ("memcpy_", _Memcpy)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("tag", i32), ("u", _OpUnion)]
+
+
+# name -> (restype, argtypes); mirrors include/mvldm.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "mvldm_abi_version": (C.c_int, []),
+    "mvldm_last_error": (C.c_char_p, []),
+    "mvldm_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(sz), C.c_char_p, C.c_int]),
+    "mvldm_igemm_fwd": (C.c_int, [C.POINTER(IgemmDesc), vp]),
+    "mvldm_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
+    "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 8 + [vp]),
+    "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp]),
+    "mvldm_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
+    "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp]),
+    "mvldm_timestep_embed_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mvldm_eltwise_fwd": (C.c_int, [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp]),
+    "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "mvldm_ddim_advance": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp]),
+    "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    "mvldm_nhwc_to_nchw": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, C.c_int, vp]),
+    "mvldm_plan_create": (C.c_int, [C.POINTER(Op), C.c_int, C.POINTER(vp)]),
+    "mvldm_plan_num_ops": (C.c_int, [vp]),
+    "mvldm_plan_run": (C.c_int, [vp, vp]),
+    "mvldm_plan_run_range": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "mvldm_plan_capture": (C.c_int, [vp, vp]),
+    "mvldm_plan_replay": (C.c_int, [vp, vp]),
+    "mvldm_plan_profile": (C.c_int, [vp, vp, C.c_int, C.POINTER(f32)]),
+    "mvldm_plan_destroy": (None, [vp]),
+}
+
+_lib = None
+
+
+class MvldmError(RuntimeError):
+    pass
+
+
+def load(required: bool = True):
+    """dlopen the in-tree shared library and attach prototypes.  No fallback: raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        if required:
+            raise MvldmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU / PyTorch fallback for the HIP path)")
+        return None
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.mvldm_abi_version() != 1:
+        raise MvldmError("libmvldm_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise MvldmError(f"mvldm error {rc}: {load().mvldm_last_error().decode()}")

@@ -1,0 +1,301 @@
+// Flash-style attention forward for CDNA4 (see include/mvldm.h: mvldm_attention_fwd).
+//
+// One workgroup = 4 waves = 128 queries of one (segment, head); K/V are streamed in 64-key tiles
+// through LDS and the score matrix never leaves the chip (the reference materialises a
+// [heads, L, L] fp32 `sim`, 839 MB at L = 5120: mvdream/attention.py:188-199).
+//
+// Both products run "transposed" so that every per-query quantity is lane-local:
+//     S^T[key][q] = K Q^T        (A = K tile from LDS, B = Q fragments held in registers)
+//     O^T[d][q]   = V^T P^T      (A = V^T tile from LDS, B = P straight from the S^T accumulators)
+// With the 32x32 MFMA accumulator layout (col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)) a lane
+// owns ONE query column: the online-softmax max / sum / rescale need no cross-lane traffic except
+// one lane^32 exchange, and P feeds the second MFMA without leaving registers -- the key order seen
+// by that MFMA is the accumulator's row order, and the V^T tile is written to LDS in the same
+// permuted key order, so no shuffle is needed.  Softmax statistics and both accumulations are fp32;
+// P is rounded to the activation dtype for the PV product (fp32 path: everything fp32 on
+// v_mfma_f32_32x32x2_f32).
+//
+// LDS: K tile [64][DP+8] (pitch = odd multiple of 16 B -> conflict-free ds_read_b128 fragment
+// reads), V^T tile [DV][64+8].  Head dims are zero-padded to DP = roundup(d,16) / DV = roundup(d,32)
+// inside LDS only -- never in HBM.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mvldm {
+
+struct AttnParams {
+    const void* q; const void* k; const void* v; void* out;
+    const int32_t* seg;
+    int ld_q, ld_k, ld_v, ld_o, heads, d;
+    float scale_log2e;
+};
+
+template <typename T> struct AttnMma;
+template <> struct AttnMma<bf16_t> {
+    using Frag = bf16x8;
+    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct AttnMma<f16_t> {
+    using Frag = f16x8;
+    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int BQ = 128, BKV = 64;
+
+// position of key `t` (0..63) inside the V^T tile for 16-bit types: the 8 consecutive slots
+// [ks*16 + hi*8, +8) must hold the keys that S^T registers (ks&1)*8 .. +8 of block ks>>1 belong to.
+__device__ __forceinline__ int vt_pos16(int t) {
+    const int kb = t >> 5, u32_ = t & 31;
+    const int g16 = u32_ >> 4, u = u32_ & 15;
+    const int hi = (u >> 2) & 1, j = (u & 3) + 4 * (u >> 3);
+    return kb * 32 + g16 * 16 + hi * 8 + j;
+}
+
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int EPC = Elt<T>::EPC;
+    constexpr int DV = (DP + 31) / 32 * 32;
+    constexpr int NDB = DV / 32;
+    constexpr int KP = F32 ? (DP + 1) : (DP + 8);     // K tile pitch (elements)
+    constexpr int VP = F32 ? (BKV + 1) : (BKV + 8);   // V^T tile pitch (elements)
+    constexpr int NCH = DP / EPC;                      // 16-byte chunks per K/V row
+    constexpr int NQ = F32 ? DP / 2 : DP / 16;         // Q fragments per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vt = Ks + BKV * KP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.y;
+    const int4 sg = reinterpret_cast<const int4*>(p.seg)[blockIdx.z];
+    const int q_row0 = sg.x, q_len = sg.y, kv_row0 = sg.z, kv_len = sg.w;
+    const int qt = blockIdx.x;
+    if (qt * BQ >= q_len) return;  // uniform per workgroup
+    const int d = p.d;
+
+    // ---- Q fragments -> registers ----
+    const int q_local = qt * BQ + wave * 32 + l31;
+    const bool q_ok = q_local < q_len;
+    const T* qp = reinterpret_cast<const T*>(p.q) + (size_t)(q_row0 + q_local) * p.ld_q + head * d;
+    typename std::conditional<F32, float, typename AttnMma<typename std::conditional<F32, bf16_t, T>::type>::Frag>::type qf[NQ];
+    if constexpr (F32) {
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) {
+            const int dk = 2 * kk + hi;
+            qf[kk] = (q_ok && dk < d) ? qp[dk] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) {
+            const int dk = kk * 16 + hi * 8;
+            u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+            if (q_ok && dk < d) raw = *reinterpret_cast<const u32x4*>(qp + dk);
+            qf[kk] = __builtin_bit_cast(typename AttnMma<T>::Frag, raw);
+        }
+    }
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const T* kbase = reinterpret_cast<const T*>(p.k) + (size_t)kv_row0 * p.ld_k + head * d;
+    const T* vbase = reinterpret_cast<const T*>(p.v) + (size_t)kv_row0 * p.ld_v + head * d;
+    const int ntile = (kv_len + BKV - 1) / BKV;
+
+    for (int kt = 0; kt < ntile; ++kt) {
+        // ---- stage K and V^T tiles ----
+        for (int idx = tid; idx < BKV * NCH; idx += 256) {
+            const int key = idx / NCH, ch = idx - key * NCH;
+            const int kg = kt * BKV + key;
+            const bool ok = kg < kv_len && ch * EPC < d;
+            Chunk<T> ck, cv;
+            if (ok) {
+                ck = load_chunk<T>(kbase + (size_t)kg * p.ld_k + ch * EPC);
+                cv = load_chunk<T>(vbase + (size_t)kg * p.ld_v + ch * EPC);
+            } else {
+                ck.zero();
+                cv.zero();
+            }
+            if constexpr (F32) {
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) {
+                    Ks[key * KP + ch * EPC + i] = ck.e[i];
+                    Vt[(ch * EPC + i) * VP + key] = cv.e[i];
+                }
+            } else {
+                *reinterpret_cast<u32x4*>(Ks + key * KP + ch * EPC) = ck.raw;
+                const int pos = vt_pos16(key);
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) Vt[(ch * EPC + i) * VP + pos] = cv.e[i];
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            const T* krow = Ks + (kb * 32 + l31) * KP;
+            if constexpr (F32) {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * kk + hi], qf[kk], s[kb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < NQ; ++kk) {
+                    const auto a = *reinterpret_cast<const typename AttnMma<T>::Frag*>(krow + kk * 16 + hi * 8);
+                    s[kb] = AttnMma<T>::mma(a, qf[kk], s[kb]);
+                }
+            }
+        }
+
+        // ---- online softmax (per query = per lane column) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float sv = s[kb][r] * p.scale_log2e;
+                sv = key < kv_len ? sv : -INFINITY;
+                s[kb][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[kb][r] - m_new);
+                s[kb][r] = pv;
+                rs += pv;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+        if constexpr (F32) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const T* vrow = Vt + (db * 32 + l31) * VP;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[key], s[kb][r], o[db], 0, 0, 0);
+                    }
+            }
+        } else {
+            typename AttnMma<T>::Frag pf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[ks][j] = from_f32<T>(s[ks >> 1][(ks & 1) * 8 + j]);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const T* vrow = Vt + (db * 32 + l31) * VP;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const auto a = *reinterpret_cast<const typename AttnMma<T>::Frag*>(vrow + ks * 16 + hi * 8);
+                    o[db] = AttnMma<T>::mma(a, pf[ks], o[db]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- normalise and write O[q][d] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (!q_ok) return;
+    T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local) * p.ld_o + head * d;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int dd = db * 32 + 8 * r4 + 4 * hi;
+            if (dd < d) {
+                if constexpr (F32) {
+                    f32x4 w = {o[db][r4 * 4 + 0] * inv, o[db][r4 * 4 + 1] * inv, o[db][r4 * 4 + 2] * inv, o[db][r4 * 4 + 3] * inv};
+                    *reinterpret_cast<f32x4*>(op + dd) = w;
+                } else {
+                    union { T e[4]; u32x2 raw; } w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w.e[e] = from_f32<T>(o[db][r4 * 4 + e] * inv);
+                    *reinterpret_cast<u32x2*>(op + dd) = w.raw;
+                }
+            }
+        }
+}
+
+template <typename T, int DP> static int launch_attn(const AttnParams& p, int n_seg, int max_q_len, hipStream_t s) {
+    constexpr bool F32 = std::is_same<T, float>::value;
+    constexpr int DV = (DP + 31) / 32 * 32;
+    constexpr int KP = F32 ? (DP + 1) : (DP + 8);
+    constexpr int VP = F32 ? (BKV + 1) : (BKV + 8);
+    constexpr int smem = (BKV * KP + DV * VP) * (int)sizeof(T);
+    auto kern = attention_kernel<T, DP>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (smem > 48 * 1024)
+            MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    dim3 grid((max_q_len + BQ - 1) / BQ, p.heads, n_seg);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+    return check_launch();
+}
+
+int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,
+                  int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len, float scale, int dtype,
+                  hipStream_t s) {
+    MVLDM_REQUIRE(q && k && v && out && seg, "attention: null pointer");
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    MVLDM_REQUIRE(head_dim > 0 && head_dim % epc == 0 && head_dim <= 160,
+                  "attention: head_dim %d unsupported (multiple of %d, <= 160)", head_dim, epc);
+    MVLDM_REQUIRE(ld_q % epc == 0 && ld_k % epc == 0 && ld_v % epc == 0 && ld_o % 4 == 0, "attention: row strides must keep 16-byte alignment");
+    if (n_seg == 0 || max_q_len == 0) return MVLDM_OK;
+    AttnParams p{q, k, v, out, seg, ld_q, ld_k, ld_v, ld_o, heads, head_dim, scale * 1.4426950408889634f};
+    const int dp = (head_dim + 15) / 16 * 16;
+    return dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        switch (dp) {
+            case 16: return launch_attn<T, 16>(p, n_seg, max_q_len, s);
+            case 32: return launch_attn<T, 32>(p, n_seg, max_q_len, s);
+            case 48: return launch_attn<T, 48>(p, n_seg, max_q_len, s);
+            case 64: return launch_attn<T, 64>(p, n_seg, max_q_len, s);
+            case 80: return launch_attn<T, 80>(p, n_seg, max_q_len, s);
+            case 96: return launch_attn<T, 96>(p, n_seg, max_q_len, s);
+            case 112: return launch_attn<T, 112>(p, n_seg, max_q_len, s);
+            case 128: return launch_attn<T, 128>(p, n_seg, max_q_len, s);
+            case 144: return launch_attn<T, 144>(p, n_seg, max_q_len, s);
+            case 160: return launch_attn<T, 160>(p, n_seg, max_q_len, s);
+            default: return set_error(MVLDM_ERR_UNSUPPORTED, "attention: head_dim %d", head_dim);
+        }
+    });
+}
+
+}  // namespace mvldm
+
+extern "C" int mvldm_attention_fwd(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v,
+                                   int ld_o, int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len,
+                                   float scale, int dtype, mvldm_stream_t stream) {
+    return mvldm::attention_run(q, k, v, out, ld_q, ld_k, ld_v, ld_o, heads, head_dim, seg, n_seg, max_q_len, scale,
+                                dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,116 @@
+// Shared device helpers for libmvldm_hip.so (gfx950 / CDNA4 only: wave64, MFMA 32x32, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/mvldm.h"
+
+namespace mvldm {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+
+int set_error(int code, const char* fmt, ...);
+#define MVLDM_CHECK_HIP(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ::mvldm::set_error(MVLDM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define MVLDM_REQUIRE(cond, ...)                                        \
+    do {                                                                \
+        if (!(cond)) return ::mvldm::set_error(MVLDM_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(MVLDM_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return MVLDM_OK;
+}
+
+// ---- element traits ------------------------------------------------------------------------------
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static constexpr int DT = MVLDM_F32;
+};
+template <> struct Elt<bf16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = MVLDM_BF16;
+};
+template <> struct Elt<f16_t> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = MVLDM_F16;
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }  // RNE for bf16/f16
+
+// A 16-byte chunk viewed as EPC elements of T.
+template <typename T> struct Chunk {
+    static constexpr int N = Elt<T>::EPC;
+    union {
+        u32x4 raw;
+        T e[N];
+    };
+    __device__ __forceinline__ Chunk() {}
+    __device__ __forceinline__ void zero() { raw = u32x4{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ float get(int i) const { return to_f32<T>(e[i]); }
+    __device__ __forceinline__ void set(int i, float v) { e[i] = from_f32<T>(v); }
+};
+
+template <typename T> __device__ __forceinline__ Chunk<T> load_chunk(const T* p) {
+    Chunk<T> c;
+    c.raw = *reinterpret_cast<const u32x4*>(p);
+    return c;
+}
+template <typename T> __device__ __forceinline__ void store_chunk(T* p, const Chunk<T>& c) {
+    *reinterpret_cast<u32x4*>(p) = c.raw;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware remap of a linear workgroup id: hardware places workgroup b on XCD b % 8, so give each
+// XCD one contiguous range of logical ids (bijective for any n).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    constexpr int X = 8;
+    int q = n / X, r = n % X;
+    int xcd = b % X, i = b / X;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + i;
+}
+
+template <typename F> inline int dispatch_dtype(int dtype, F&& f) {
+    switch (dtype) {
+        case MVLDM_F32: return f(float{});
+        case MVLDM_BF16: return f(bf16_t{});
+        case MVLDM_F16: return f(f16_t{});
+        default: return set_error(MVLDM_ERR_ARG, "unknown dtype %d", dtype);
+    }
+}
+inline size_t dtype_size(int dtype) { return dtype == MVLDM_F32 ? 4 : 2; }
+
+}  // namespace mvldm

@@ -1,0 +1,466 @@
+// Implicit-GEMM convolution / Linear on CDNA4 matrix cores (see include/mvldm.h: mvldm_igemm_fwd).
+//
+//   out[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] + row_bias[img(m)][n] ) * scale + residual[m][n]
+//
+// m = (image, oy, ox) output pixel, k = (tap, channel).  A is never materialised: every 16-byte
+// chunk of a K-tile row is fetched straight from the NHWC activation(s) -- zero for padding taps,
+// from the second source for the skip-concat channels, from (iy>>1, ix>>1) for the fused nearest
+// upsample.  W is the pre-packed K-major weight.  Both tiles are staged through LDS (double
+// buffered, register prefetch of the next K-tile while MFMAs run on the current one) and consumed by
+// v_mfma_f32_32x32x16_{bf16,f16} / v_mfma_f32_32x32x2_f32 with fp32 accumulation.
+//
+// LDS layout (16-bit types): 128-byte rows of 8 x 16-byte chunks, chunk index XOR-swizzled with
+// (row>>1)&7 so that the 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-byte
+// slots of the 256-byte bank row (conflict-free); fp32: rows of 32 floats at pitch 33.
+// Workgroup -> tile mapping is XCD-aware: each of the 8 XCDs owns a contiguous range of
+// (split, n-tile, m-tile) ids with m fastest, so one weight tile is streamed from HBM by one XCD only.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mvldm {
+
+struct IgemmParams {
+    const void* src0; const void* src1; const void* weight;
+    const float* bias; const float* row_bias; const void* residual; void* dst; float* ws;
+    int c0, c1, ctot;
+    int n_img, h_in, w_in, h_out, w_out, hw_out;
+    int ksize, stride, pad, upsample;
+    int M, n_out, n_pad, n_dst, k_pad, taps;
+    int row_bias_ld, epilogue, dst_f32;
+    float out_scale;
+    int splitk, k_tiles, k_tiles_per_split;
+    int tiles_m, tiles_n;
+};
+
+// ---- per-dtype MFMA + LDS policy -------------------------------------------------------------------
+template <typename T> struct Mma;
+
+template <typename T16, typename FragT> struct Mma16 {
+    static constexpr int KI = 16;        // K per MFMA
+    static constexpr int BK = 64;        // K per LDS tile
+    static constexpr int PITCH = 128;    // bytes per LDS row
+    using Frag = FragT;
+    static __device__ __forceinline__ void store(char* tile, int r, int kc, u32x4 v) {
+        *reinterpret_cast<u32x4*>(tile + r * PITCH + ((kc ^ ((r >> 1) & 7)) << 4)) = v;
+    }
+    static __device__ __forceinline__ Frag load(const char* tile, int r, int kk, int hi) {
+        const int kc = kk * 2 + hi;
+        return *reinterpret_cast<const Frag*>(tile + r * PITCH + ((kc ^ ((r >> 1) & 7)) << 4));
+    }
+};
+template <> struct Mma<bf16_t> : Mma16<bf16_t, bf16x8> {
+    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> : Mma16<f16_t, f16x8> {
+    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KI = 2;
+    static constexpr int BK = 32;
+    static constexpr int PITCH = 33 * 4;
+    using Frag = float;
+    static __device__ __forceinline__ void store(char* tile, int r, int kc, u32x4 v) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(tile + r * PITCH + kc * 16);
+        p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3];
+    }
+    static __device__ __forceinline__ Frag load(const char* tile, int r, int kk, int hi) {
+        return *reinterpret_cast<const float*>(tile + r * PITCH + (kk * 2 + hi) * 4);
+    }
+    static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+
+// packed weight row -> original output column (GEGLU rows alternate [value|gate] in blocks of 32)
+__device__ __forceinline__ int orig_col(int n_packed, int n_out, bool geglu) {
+    if (!geglu) return n_packed;
+    const int blk = n_packed >> 5, w = n_packed & 31;
+    return (blk & 1) ? (n_out >> 1) + (blk >> 1) * 32 + w : (blk >> 1) * 32 + w;
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const IgemmParams& p, int m, int n_dst_col, float v) {
+    // v already includes bias/row_bias/activation
+    v *= p.out_scale;
+    const size_t o = (size_t)m * p.n_dst + n_dst_col;
+    if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[o]);
+    if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
+    else reinterpret_cast<T*>(p.dst)[o] = from_f32<T>(v);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p) {
+    using M_ = Mma<T>;
+    constexpr int NT = WM * WN * 64;
+    constexpr int EPC = Elt<T>::EPC;
+    constexpr int BK = M_::BK;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * M_::PITCH, B_BYTES = BN * M_::PITCH;
+    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+    static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "bad tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int ntile = p.tiles_m * p.tiles_n;
+    int lid = xcd_remap(blockIdx.x, ntile * p.splitk);
+    const int split = lid / ntile;
+    lid -= split * ntile;
+    const int tn = lid / p.tiles_m, tm = lid - tn * p.tiles_m;
+    const int kt0 = split * p.k_tiles_per_split;
+    const int kt1 = min(kt0 + p.k_tiles_per_split, p.k_tiles);
+
+    // ---- loader coordinates (fixed per thread across the K loop) ----
+    const int kc = tid & 7, r0 = tid >> 3;
+    int a_img[A_IT], a_y[A_IT], a_x[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = tm * BM + r0 + it * (NT / 8);
+        if (m < p.M) {
+            const int img = m / p.hw_out, rem = m - img * p.hw_out;
+            const int oy = rem / p.w_out;
+            a_img[it] = img;
+            a_y[it] = oy * p.stride - p.pad;
+            a_x[it] = (rem - oy * p.w_out) * p.stride - p.pad;
+        } else {
+            a_img[it] = -1; a_y[it] = 0; a_x[it] = 0;
+        }
+    }
+    const T* wbase = reinterpret_cast<const T*>(p.weight) + (size_t)(tn * BN + r0) * p.k_pad + kc * EPC;
+    const int hs = p.upsample ? 2 * p.h_in : p.h_in, wsz = p.upsample ? 2 * p.w_in : p.w_in;
+
+    u32x4 areg[A_IT], breg[B_IT];
+    auto load_tile = [&](int kt) {
+        const int ke = kt * BK + kc * EPC;
+        const int tap = ke / p.ctot;
+        const int c = ke - tap * p.ctot;
+        const bool tap_ok = tap < p.taps;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const bool from0 = c < p.c0;
+        const T* sbase = from0 ? reinterpret_cast<const T*>(p.src0) + c
+                               : reinterpret_cast<const T*>(p.src1) + (c - p.c0);
+        const int cs = from0 ? p.c0 : p.c1;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int iy = a_y[it] + ky, ix = a_x[it] + kx;
+            const bool ok = tap_ok && a_img[it] >= 0 && iy >= 0 && iy < hs && ix >= 0 && ix < wsz;
+            if (p.upsample) { iy >>= 1; ix >>= 1; }
+            if (ok) {
+                const size_t off = ((size_t)(a_img[it] * p.h_in + iy) * p.w_in + ix) * cs;
+                areg[it] = *reinterpret_cast<const u32x4*>(sbase + off);
+            } else {
+                areg[it] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int n = tn * BN + r0 + it * (NT / 8);
+            if (n < p.n_pad)
+                breg[it] = *reinterpret_cast<const u32x4*>(wbase + (size_t)it * (NT / 8) * p.k_pad + (size_t)kt * BK);
+            else
+                breg[it] = u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* at = smem + stage * (A_BYTES + B_BYTES);
+        char* bt = at + A_BYTES;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) M_::store(at, r0 + it * (NT / 8), kc, areg[it]);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) M_::store(bt, r0 + it * (NT / 8), kc, breg[it]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = kt + 1 < kt1;
+        if (more) load_tile(kt + 1);
+        const char* at = smem + cur * (A_BYTES + B_BYTES);
+        const char* bt = at + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / M_::KI; ++kk) {
+            typename M_::Frag a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ----
+    const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
+    if (p.splitk > 1) {
+        float* ws = p.ws + (size_t)split * p.M * p.n_pad;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = tn * BN + wn * (BN / WN) + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m < p.M && n < p.n_pad) ws[(size_t)m * p.n_pad + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (geglu) {
+            if constexpr (TN % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int nb = tn * BN + wn * (BN / WN) + j * 32;  // packed col of the value block
+                    const int col = (nb >> 6) * 32 + l31;             // output column
+                    if (col >= p.n_dst) continue;
+                    const float bv = p.bias ? p.bias[col] : 0.f;
+                    const float bg = p.bias ? p.bias[p.n_dst + col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (m >= p.M) continue;
+                        epilogue_store<T>(p, m, col, (acc[i][j][r] + bv) * gelu_erf_f(acc[i][j + 1][r] + bg));
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = tn * BN + wn * (BN / WN) + j * 32 + l31;
+                if (n >= p.n_out) continue;
+                const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m >= p.M) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (p.row_bias) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
+                    if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
+                    epilogue_store<T>(p, m, n, v);
+                }
+            }
+        }
+    }
+}
+
+// split-K: sum the fp32 partial slabs and run the same epilogue (deterministic, no atomics)
+template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmParams p) {
+    const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
+    const size_t total = (size_t)p.M * p.n_dst;
+    const size_t slab = (size_t)p.M * p.n_pad;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / p.n_dst), col = (int)(idx - (size_t)m * p.n_dst);
+        float v;
+        if (geglu) {
+            const int nv = (col >> 5) * 64 + (col & 31), ng = nv + 32;
+            float a = 0.f, g = 0.f;
+            for (int s = 0; s < p.splitk; ++s) {
+                a += p.ws[s * slab + (size_t)m * p.n_pad + nv];
+                g += p.ws[s * slab + (size_t)m * p.n_pad + ng];
+            }
+            if (p.bias) { a += p.bias[col]; g += p.bias[p.n_dst + col]; }
+            v = a * gelu_erf_f(g);
+        } else {
+            float a = 0.f;
+            for (int s = 0; s < p.splitk; ++s) a += p.ws[s * slab + (size_t)m * p.n_pad + col];
+            if (p.bias) a += p.bias[col];
+            if (p.row_bias) a += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + col];
+            if (p.epilogue == MVLDM_EPI_SILU) a = silu_f(a);
+            v = a;
+        }
+        epilogue_store<T>(p, m, col, v);
+    }
+}
+
+// ---- weight packing -------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_out,
+                                                          int c_in, int ksize, int c_pad, int n_pad, int k_pad, int geglu) {
+    const size_t total = (size_t)n_pad * k_pad;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int np = (int)(idx / k_pad), k = (int)(idx - (size_t)np * k_pad);
+        const int tap = k / c_pad, c = k - tap * c_pad;
+        const int n = orig_col(np, n_out, geglu != 0);
+        float v = 0.f;
+        if (n < n_out && tap < ksize * ksize && c < c_in)
+            v = src[((size_t)n * c_in + c) * (ksize * ksize) + tap];
+        dst[idx] = from_f32<T>(v);
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+struct TileCfg { int bm, bn, threads; };
+static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64, 128, 256}, {64, 64, 128}, {32, 64, 64}};
+constexpr int kNumTiles = 5;
+
+template <typename T, int BM, int BN, int WM, int WN> static int launch_tile(const IgemmParams& p, hipStream_t s) {
+    constexpr int smem = 2 * (BM + BN) * Mma<T>::PITCH;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (smem > 48 * 1024)
+            MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splitk), dim3(WM * WN * 64), smem, s, p);
+    return check_launch();
+}
+
+template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch_tile<T, 128, 128, 2, 2>(p, s);
+        case 2: return launch_tile<T, 128, 64, 4, 1>(p, s);
+        case 3: return launch_tile<T, 64, 128, 2, 2>(p, s);
+        case 4: return launch_tile<T, 64, 64, 2, 1>(p, s);
+        case 5: return launch_tile<T, 32, 64, 1, 1>(p, s);
+        default: return set_error(MVLDM_ERR_ARG, "igemm: bad tile %d", tile);
+    }
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Pick tile + split-K.  Target: >= ~2 workgroups per CU (256 CUs) without shredding K below 4 tiles.
+static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& tile, int& splitk, size_t ws_bytes) {
+    const int target = 512;
+    if (tile == 0) {
+        double best = -1;
+        for (int t = 1; t <= kNumTiles; ++t) {
+            const int tm = cdiv(M, kTiles[t].bm), tn = cdiv(d.n_pad, kTiles[t].bn);
+            const double util = (double)M * d.n_pad / ((double)tm * kTiles[t].bm * tn * kTiles[t].bn);
+            const int wgs = tm * tn;
+            int sk = 1;
+            if (wgs < target) sk = std::min(std::max(k_tiles / 4, 1), cdiv(target, wgs));
+            const double fill = std::min(1.0, (double)wgs * sk / target);
+            // bigger tiles reuse operands better: mild preference
+            const double reuse = 1.0 - 8.0 / (kTiles[t].bm + kTiles[t].bn) * 4.0;
+            const double score = util * (0.35 + 0.65 * fill) * (0.6 + 0.4 * reuse) * (sk > 1 ? 0.92 : 1.0);
+            if (score > best) { best = score; tile = t; }
+        }
+    }
+    const int tm = cdiv(M, kTiles[tile].bm), tn = cdiv(d.n_pad, kTiles[tile].bn);
+    if (splitk == 0) {
+        splitk = 1;
+        const int wgs = tm * tn;
+        if (wgs < target) splitk = std::min(std::max(k_tiles / 4, 1), cdiv(target, wgs));
+        if (d.workspace == nullptr) splitk = 1;
+        while (splitk > 1 && (size_t)splitk * M * d.n_pad * sizeof(float) > ws_bytes) --splitk;
+    }
+    splitk = std::max(1, std::min(splitk, k_tiles));
+}
+
+static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
+    const int epc = d.act_dtype == MVLDM_F32 ? 4 : 8;
+    const int bk = d.act_dtype == MVLDM_F32 ? 32 : 64;
+    MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
+    MVLDM_REQUIRE(d.ksize == 1 || d.ksize == 3, "igemm: ksize %d", d.ksize);
+    MVLDM_REQUIRE(d.stride == 1 || d.stride == 2, "igemm: stride %d", d.stride);
+    MVLDM_REQUIRE(d.c0 % epc == 0 && d.c1 % epc == 0 && d.c0 > 0, "igemm: channels (%d,%d) must be multiples of %d", d.c0, d.c1, epc);
+    MVLDM_REQUIRE((d.c1 == 0) == (d.src1 == nullptr), "igemm: src1/c1 mismatch");
+    MVLDM_REQUIRE(d.k_pad % bk == 0 && d.k_pad >= d.ksize * d.ksize * (d.c0 + d.c1), "igemm: k_pad %d", d.k_pad);
+    MVLDM_REQUIRE(d.n_pad % 64 == 0 && d.n_pad >= d.n_out, "igemm: n_pad %d (n_out %d)", d.n_pad, d.n_out);
+    MVLDM_REQUIRE(d.dst_dtype == d.act_dtype || d.dst_dtype == MVLDM_F32, "igemm: dst dtype");
+    if (d.epilogue == MVLDM_EPI_GEGLU)
+        MVLDM_REQUIRE(d.n_out % 64 == 0 && !d.row_bias, "igemm: GEGLU needs n_out %% 64 == 0");
+    p.src0 = d.src0; p.src1 = d.src1; p.weight = d.weight; p.bias = d.bias; p.row_bias = d.row_bias;
+    p.residual = d.residual; p.dst = d.dst; p.ws = d.workspace;
+    p.c0 = d.c0; p.c1 = d.c1; p.ctot = d.c0 + d.c1;
+    p.n_img = d.n_img; p.h_in = d.h_in; p.w_in = d.w_in; p.h_out = d.h_out; p.w_out = d.w_out;
+    p.hw_out = d.h_out * d.w_out;
+    p.ksize = d.ksize; p.stride = d.stride; p.pad = d.pad; p.upsample = d.upsample; p.taps = d.ksize * d.ksize;
+    p.M = d.n_img * p.hw_out; p.n_out = d.n_out; p.n_pad = d.n_pad; p.k_pad = d.k_pad;
+    p.n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
+    p.row_bias_ld = d.row_bias_ld; p.epilogue = d.epilogue; p.dst_f32 = d.dst_dtype == MVLDM_F32;
+    p.out_scale = d.out_scale;
+    p.k_tiles = d.k_pad / bk;
+    tile = d.tile;
+    int splitk = d.splitk;
+    MVLDM_REQUIRE(tile >= 0 && tile <= kNumTiles && splitk >= 0, "igemm: tile/splitk");
+    choose_config(d, p.M, p.k_tiles, tile, splitk, d.workspace_bytes);
+    if (splitk > 1)
+        MVLDM_REQUIRE(d.workspace && (size_t)splitk * p.M * d.n_pad * sizeof(float) <= d.workspace_bytes,
+                      "igemm: split-K workspace too small");
+    p.splitk = splitk;
+    p.k_tiles_per_split = cdiv(p.k_tiles, splitk);
+    p.splitk = cdiv(p.k_tiles, p.k_tiles_per_split);  // drop empty splits
+    p.tiles_m = cdiv(p.M, kTiles[tile].bm);
+    p.tiles_n = cdiv(d.n_pad, kTiles[tile].bn);
+    return MVLDM_OK;
+}
+
+int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
+    IgemmParams p;
+    int tile = 0;
+    int rc = fill_params(d, p, tile);
+    if (rc) return rc;
+    if (p.M == 0) return MVLDM_OK;
+    rc = dispatch_dtype(d.act_dtype, [&](auto t) {
+        using T = decltype(t);
+        int r = launch_igemm<T>(p, tile, s);
+        if (r) return r;
+        if (p.splitk > 1) {
+            const size_t total = (size_t)p.M * p.n_dst;
+            const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+            hipLaunchKernelGGL(igemm_splitk_reduce<T>, dim3(blocks), dim3(256), 0, s, p);
+            return check_launch();
+        }
+        return (int)MVLDM_OK;
+    });
+    return rc;
+}
+
+}  // namespace mvldm
+
+using namespace mvldm;
+
+extern "C" int mvldm_igemm_fwd(const mvldm_igemm_desc* d, mvldm_stream_t stream) {
+    MVLDM_REQUIRE(d != nullptr, "igemm: null desc");
+    return igemm_run(*d, (hipStream_t)stream);
+}
+
+extern "C" size_t mvldm_igemm_workspace_bytes(const mvldm_igemm_desc* d) {
+    if (!d) return 0;
+    const size_t M = (size_t)d->n_img * d->h_out * d->w_out;
+    // the heuristic never splits deeper than ~512 workgroups' worth; 16 slabs is a safe ceiling
+    return (size_t)16 * M * d->n_pad * sizeof(float);
+}
+
+extern "C" int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksize, int c_pad, int n_pad,
+                                 int k_pad, int geglu, int dst_dtype, mvldm_stream_t stream) {
+    MVLDM_REQUIRE(src && dst && c_pad >= c_in && n_pad >= n_out && k_pad >= ksize * ksize * c_pad, "pack_weight: bad dims");
+    MVLDM_REQUIRE(!geglu || n_out % 64 == 0, "pack_weight: GEGLU needs n_out %% 64 == 0");
+    const size_t total = (size_t)n_pad * k_pad;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+    return dispatch_dtype(dst_dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                           reinterpret_cast<T*>(dst), n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu);
+        return check_launch();
+    });
+}

@@ -1,0 +1,204 @@
+// Small HBM-bound kernels: sinusoidal timestep projection, elementwise SiLU / dtype conversion,
+// fused CFG + DDIM update, DDIM step bookkeeping, NCHW<->NHWC boundary plumbing (include/mvldm.h).
+#include <algorithm>
+
+#include "common.h"
+
+namespace mvldm {
+
+template <typename T>
+__global__ __launch_bounds__(256) void temb_kernel(const int64_t* __restrict__ ts, const float* __restrict__ freqs,
+                                                   T* __restrict__ out, int n, int dim, int flip) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * dim) return;
+    const int i = idx / dim, j = idx - i * dim;
+    const int fj = j < half ? j : j - half;
+    const float arg = (float)ts[i] * freqs[fj];  // timesteps[:, None].float() * emb[None, :]
+    const bool use_cos = flip ? (j < half) : (j >= half);
+    out[idx] = from_f32<T>(use_cos ? cosf(arg) : sinf(arg));
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void eltwise_kernel(const TS* __restrict__ x, TD* __restrict__ y, size_t n, int op) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = to_f32<TS>(x[i]);
+        if (op == MVLDM_ELT_SILU) v = silu_f(v);
+        y[i] = from_f32<TD>(v);
+    }
+}
+
+// fp32, separately rounded operations in the order of diffusers' DDIMScheduler.step (eta = 0):
+// the mul/sub/div/add sequence must not be contracted into FMAs to stay bit-identical to torch.
+template <typename TU>
+__global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ eps, const float* __restrict__ x_t,
+                                                   float* __restrict__ x_next, const int32_t* __restrict__ cond_img,
+                                                   const int32_t* __restrict__ uncond_img, int n_tgt, int hw, int c,
+                                                   float cfg_scale, const float* __restrict__ coef,
+                                                   const int32_t* __restrict__ step_ptr, TU* __restrict__ unet_in,
+                                                   int unet_in_c) {
+    const int step = *step_ptr;
+    const float sb = coef[step * 4 + 0], sa = coef[step * 4 + 1], sp = coef[step * 4 + 2], sd = coef[step * 4 + 3];
+    const size_t per = (size_t)hw * c, total = (size_t)n_tgt * per;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int t = (int)(idx / per);
+        const size_t rem = idx - (size_t)t * per;
+        const int ci = cond_img[t];
+        const float ec = eps[(size_t)ci * per + rem];
+        float e = ec;
+        int ui = -1;
+        if (uncond_img) {
+            ui = uncond_img[t];
+            const float eu = eps[(size_t)ui * per + rem];
+            e = __fadd_rn(eu, __fmul_rn(cfg_scale, __fsub_rn(ec, eu)));
+        }
+        const float x = x_t[idx];
+        const float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(sb, e)), sa);
+        const float xn = __fadd_rn(__fmul_rn(sp, x0), __fmul_rn(sd, e));
+        x_next[idx] = xn;
+        if (unet_in) {
+            const int pix = (int)(rem / c), ch = (int)(rem - (size_t)pix * c);
+            unet_in[((size_t)ci * hw + pix) * unet_in_c + ch] = from_f32<TU>(xn);
+            if (ui >= 0) unet_in[((size_t)ui * hw + pix) * unet_in_c + ch] = from_f32<TU>(xn);
+        }
+    }
+}
+
+__global__ void ddim_advance_kernel(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps,
+                                    const int32_t* tgt_rows, int n_rows) {
+    const int next = *step_ptr + 1;
+    __syncthreads();
+    const int64_t t = t_table[next < n_steps ? next : n_steps - 1];
+    for (int i = threadIdx.x; i < n_rows; i += blockDim.x) timesteps[tgt_rows[i]] = t;
+    if (threadIdx.x == 0) *step_ptr = next;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_img,
+                                                           int c, int hw, int dst_c, int dst_c_off) {
+    const size_t total = (size_t)n_img * hw * c;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        // idx enumerates the destination (pixel-major, channel fastest)
+        const int ch = (int)(idx % c);
+        const size_t pi = idx / c;
+        const int pix = (int)(pi % hw), img = (int)(pi / hw);
+        dst[((size_t)img * hw + pix) * dst_c + dst_c_off + ch] = from_f32<T>(src[((size_t)img * c + ch) * hw + pix]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int n_img,
+                                                           int c, int hw, int src_c, int src_c_off, float scale,
+                                                           float shift, int clamp01) {
+    const size_t total = (size_t)n_img * hw * c;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        // idx enumerates the destination (channel-major, pixel fastest)
+        const int pix = (int)(idx % hw);
+        const size_t ic = idx / hw;
+        const int ch = (int)(ic % c), img = (int)(ic / c);
+        float v = to_f32<T>(src[((size_t)img * hw + pix) * src_c + src_c_off + ch]) * scale + shift;
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        dst[idx] = v;
+    }
+}
+
+static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
+
+int temb_run(const int64_t* ts, const float* freqs, void* out, int n, int dim, int flip, int dst_dtype, hipStream_t s) {
+    MVLDM_REQUIRE(ts && freqs && out && dim % 2 == 0, "timestep_embed: bad arguments");
+    if (n == 0) return MVLDM_OK;
+    return dispatch_dtype(dst_dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(temb_kernel<T>, dim3((n * dim + 255) / 256), dim3(256), 0, s, ts, freqs, reinterpret_cast<T*>(out), n, dim, flip);
+        return check_launch();
+    });
+}
+
+int eltwise_run(const void* x, void* y, size_t n, int op, int src_dtype, int dst_dtype, hipStream_t s) {
+    MVLDM_REQUIRE(x && y, "eltwise: null pointer");
+    if (n == 0) return MVLDM_OK;
+    return dispatch_dtype(src_dtype, [&](auto ts_) {
+        using TS = decltype(ts_);
+        return dispatch_dtype(dst_dtype, [&](auto td_) {
+            using TD = decltype(td_);
+            hipLaunchKernelGGL((eltwise_kernel<TS, TD>), dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const TS*>(x),
+                               reinterpret_cast<TD*>(y), n, op);
+            return check_launch();
+        });
+    });
+}
+
+int ddim_run(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img, const int32_t* uncond_img,
+             int n_tgt, int hw, int c, float cfg_scale, const float* coef, const int32_t* step_ptr, void* unet_in,
+             int unet_in_c, int unet_in_dtype, hipStream_t s) {
+    MVLDM_REQUIRE(eps && x_t && x_next && cond_img && coef && step_ptr, "ddim: null pointer");
+    const size_t total = (size_t)n_tgt * hw * c;
+    if (total == 0) return MVLDM_OK;
+    return dispatch_dtype(unet_in_dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(ddim_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, eps, x_t, x_next, cond_img, uncond_img,
+                           n_tgt, hw, c, cfg_scale, coef, step_ptr, reinterpret_cast<T*>(unet_in), unet_in_c);
+        return check_launch();
+    });
+}
+
+int advance_run(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps, const int32_t* tgt_rows,
+                int n_rows, hipStream_t s) {
+    MVLDM_REQUIRE(step_ptr && t_table && n_steps > 0, "ddim_advance: bad arguments");
+    MVLDM_REQUIRE(n_rows == 0 || (timesteps && tgt_rows), "ddim_advance: null rows");
+    hipLaunchKernelGGL(ddim_advance_kernel, dim3(1), dim3(64), 0, s, step_ptr, t_table, n_steps, timesteps, tgt_rows, n_rows);
+    return check_launch();
+}
+
+int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off, int dst_dtype, hipStream_t s) {
+    MVLDM_REQUIRE(src && dst && dst_c_off + c <= dst_c, "nchw_to_nhwc: bad arguments");
+    const size_t total = (size_t)n_img * hw * c;
+    if (total == 0) return MVLDM_OK;
+    return dispatch_dtype(dst_dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, src, reinterpret_cast<T*>(dst), n_img, c, hw, dst_c, dst_c_off);
+        return check_launch();
+    });
+}
+
+int to_nchw_run(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off, int src_dtype, float scale,
+                float shift, int clamp01, hipStream_t s) {
+    MVLDM_REQUIRE(src && dst && src_c_off + c <= src_c, "nhwc_to_nchw: bad arguments");
+    const size_t total = (size_t)n_img * hw * c;
+    if (total == 0) return MVLDM_OK;
+    return dispatch_dtype(src_dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, reinterpret_cast<const T*>(src), dst, n_img, c, hw, src_c, src_c_off, scale, shift, clamp01);
+        return check_launch();
+    });
+}
+
+}  // namespace mvldm
+
+using namespace mvldm;
+extern "C" int mvldm_timestep_embed_fwd(const int64_t* timesteps, const float* freqs, void* out, int n, int dim,
+                                        int flip_sin_to_cos, int dst_dtype, mvldm_stream_t stream) {
+    return temb_run(timesteps, freqs, out, n, dim, flip_sin_to_cos, dst_dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_eltwise_fwd(const void* x, void* y, size_t n, int op, int src_dtype, int dst_dtype, mvldm_stream_t stream) {
+    return eltwise_run(x, y, n, op, src_dtype, dst_dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_ddim_cfg_step(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img,
+                                   const int32_t* uncond_img, int n_tgt, int hw, int c, float cfg_scale, const float* coef,
+                                   const int32_t* step_ptr, void* unet_in, int unet_in_c, int unet_in_dtype,
+                                   mvldm_stream_t stream) {
+    return ddim_run(eps, x_t, x_next, cond_img, uncond_img, n_tgt, hw, c, cfg_scale, coef, step_ptr, unet_in, unet_in_c,
+                    unet_in_dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_ddim_advance(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps,
+                                  const int32_t* tgt_rows, int n_rows, mvldm_stream_t stream) {
+    return advance_run(step_ptr, t_table, n_steps, timesteps, tgt_rows, n_rows, (hipStream_t)stream);
+}
+extern "C" int mvldm_nchw_to_nhwc(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off,
+                                  int dst_dtype, mvldm_stream_t stream) {
+    return to_nhwc_run(src, dst, n_img, c, hw, dst_c, dst_c_off, dst_dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_nhwc_to_nchw(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off,
+                                  int src_dtype, float scale, float shift, int clamp01, mvldm_stream_t stream) {
+    return to_nchw_run(src, dst, n_img, c, hw, src_c, src_c_off, src_dtype, scale, shift, clamp01, (hipStream_t)stream);
+}

@@ -1,0 +1,232 @@
+// GroupNorm(+SiLU) and LayerNorm for NHWC / token-major activations (see include/mvldm.h).
+//
+// GroupNorm: two launches.  (1) `gn_stats`: each workgroup streams a contiguous slab of rows of one
+// image with 16-byte loads (fully coalesced), every thread owning one fixed 16-byte channel chunk
+// column so its per-channel sum / sum-of-squares stay in registers (fp64: the variance is exact to
+// double round-off, no E[x^2]-E[x]^2 cancellation issue), then folds channels into the 32 groups
+// through LDS and writes one partial per (image, slab, group).  (2) `gn_apply`: re-reads the slab
+// (L2/MALL resident at these sizes), turns the partials into per-channel scale/shift in LDS and
+// writes normalised (+SiLU) activations.  HBM-bound: algorithmic traffic = 2 reads + 1 write.
+//
+// LayerNorm: one wave per token row, row held in registers, two-pass mean / centred variance with
+// wave64 butterfly reductions, fp32.
+#include "common.h"
+
+namespace mvldm {
+
+// ---------------------------------------------------------------------------------------------- GN
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ partial, int hw,
+                                                       int c, int groups, int rows_per_chunk, int nchunk) {
+    constexpr int EPC = Elt<T>::EPC;
+    __shared__ double s_sum[64], s_sq[64];  // groups <= 64
+    const int img = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const int ncc = c / EPC;                 // 16-byte chunk columns per row
+    const int cpg = c / groups;
+    const int tid = threadIdx.x;
+    if (tid < 64) { s_sum[tid] = 0.0; s_sq[tid] = 0.0; }
+    __syncthreads();
+    const int r_begin = chunk * rows_per_chunk, r_end = min(hw, r_begin + rows_per_chunk);
+    // thread -> (row lane, chunk column); the block covers R rows per sweep.  If ncc > blockDim the
+    // columns themselves are swept as well.
+    const int nthr = blockDim.x;
+    for (int cc0 = 0; cc0 < ncc; cc0 += nthr) {
+        const int span = min(ncc - cc0, nthr);   // columns handled in this sweep
+        const int R = max(1, nthr / span);
+        const int cc = cc0 + tid % span, rl = tid / span;
+        double s[EPC], q[EPC];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) { s[i] = 0.0; q[i] = 0.0; }
+        if (rl < R) {
+            const T* base = x + ((size_t)img * hw) * c + (size_t)cc * EPC;
+            for (int r = r_begin + rl; r < r_end; r += R) {
+                const Chunk<T> v = load_chunk<T>(base + (size_t)r * c);
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) {
+                    const double f = (double)v.get(i);
+                    s[i] += f;
+                    q[i] += f * f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                const int g = (cc * EPC + i) / cpg;
+                atomicAdd(&s_sum[g], s[i]);
+                atomicAdd(&s_sq[g], q[i]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        double* o = partial + (((size_t)img * nchunk + chunk) * groups + tid) * 2;
+        o[0] = s_sum[tid];
+        o[1] = s_sq[tid];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const double* __restrict__ partial, int hw, int c, int groups,
+                                                       int rows_per_chunk, int nchunk, float eps, int silu) {
+    constexpr int EPC = Elt<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s_scale = reinterpret_cast<float*>(smem_raw);  // [c]
+    float* s_shift = s_scale + c;                          // [c]
+    float* s_mean = s_shift + c;                           // [groups]
+    float* s_rstd = s_mean + groups;                       // [groups]
+    const int img = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const int tid = threadIdx.x;
+    const int cpg = c / groups;
+    if (tid < groups) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const double* pp = partial + (((size_t)img * nchunk + k) * groups + tid) * 2;
+            s += pp[0];
+            q += pp[1];
+        }
+        const double n = (double)hw * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += blockDim.x) {
+        const int g = ch / cpg;
+        const float sc = s_rstd[g] * gamma[ch];
+        s_scale[ch] = sc;
+        s_shift[ch] = beta[ch] - s_mean[g] * sc;
+    }
+    __syncthreads();
+    const int ncc = c / EPC;
+    const int r_begin = chunk * rows_per_chunk, r_end = min(hw, r_begin + rows_per_chunk);
+    const size_t total = (size_t)(r_end - r_begin) * ncc;
+    const T* xb = x + ((size_t)img * hw + r_begin) * c;
+    T* yb = y + ((size_t)img * hw + r_begin) * c;
+    for (size_t idx = tid; idx < total; idx += blockDim.x) {
+        const int cc = (int)(idx % ncc);
+        const Chunk<T> v = load_chunk<T>(xb + idx * EPC);
+        Chunk<T> o;
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) {
+            float f = v.get(i) * s_scale[cc * EPC + i] + s_shift[cc * EPC + i];
+            if (silu) f = silu_f(f);
+            o.set(i, f);
+        }
+        store_chunk<T>(yb + idx * EPC, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LN
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int c, float eps) {
+    constexpr int EPC = Elt<T>::EPC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ncc = c / EPC;
+    const T* xr = x + (size_t)row * c;
+    Chunk<T> v[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int cc = lane + k * 64;
+        if (cc < ncc) {
+            v[k] = load_chunk<T>(xr + cc * EPC);
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) s += v[k].get(i);
+        }
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int cc = lane + k * 64;
+        if (cc < ncc) {
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                const float d = v[k].get(i) - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+    T* yr = y + (size_t)row * c;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int cc = lane + k * 64;
+        if (cc < ncc) {
+            Chunk<T> o;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                const int ch = cc * EPC + i;
+                o.set(i, (v[k].get(i) - mean) * rstd * gamma[ch] + beta[ch]);
+            }
+            store_chunk<T>(yr + cc * EPC, o);
+        }
+    }
+}
+
+int groupnorm_run(const void* x, void* y, const float* gamma, const float* beta, int n_img, int hw, int c, int groups,
+                  float eps, int silu, int dtype, void* stats_ws, hipStream_t s) {
+    MVLDM_REQUIRE(x && y && gamma && beta && stats_ws, "groupnorm: null pointer");
+    MVLDM_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "groupnorm: c=%d groups=%d", c, groups);
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    MVLDM_REQUIRE(c % epc == 0, "groupnorm: c=%d must be a multiple of %d", c, epc);
+    if (n_img == 0 || hw == 0) return MVLDM_OK;
+    // slabs: enough workgroups to cover the chip, at least 8 rows each
+    int nchunk = std::min(MVLDM_GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, (1024 + n_img - 1) / n_img)));
+    const int rows_per_chunk = (hw + nchunk - 1) / nchunk;
+    nchunk = (hw + rows_per_chunk - 1) / rows_per_chunk;
+    const size_t smem = (size_t)(2 * c + 2 * groups) * sizeof(float);
+    return dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(n_img * nchunk), dim3(256), 0, s, reinterpret_cast<const T*>(x),
+                           reinterpret_cast<double*>(stats_ws), hw, c, groups, rows_per_chunk, nchunk);
+        int rc = check_launch();
+        if (rc) return rc;
+        hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(n_img * nchunk), dim3(256), smem, s, reinterpret_cast<const T*>(x),
+                           reinterpret_cast<T*>(y), gamma, beta, reinterpret_cast<const double*>(stats_ws), hw, c, groups,
+                           rows_per_chunk, nchunk, eps, silu);
+        return check_launch();
+    });
+}
+
+int layernorm_run(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps, int dtype,
+                  hipStream_t s) {
+    MVLDM_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    MVLDM_REQUIRE(c % epc == 0, "layernorm: c=%d must be a multiple of %d", c, epc);
+    const int ncc = c / epc;
+    MVLDM_REQUIRE(ncc <= 64 * 16, "layernorm: c=%d too wide", c);
+    if (rows == 0) return MVLDM_OK;
+    const int blocks = (rows + 3) / 4;
+    return dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        const T* xp = reinterpret_cast<const T*>(x);
+        T* yp = reinterpret_cast<T*>(y);
+        if (ncc <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);
+        else if (ncc <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);
+        else if (ncc <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);
+        else if (ncc <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);
+        else hipLaunchKernelGGL((layernorm_kernel<T, 16>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);
+        return check_launch();
+    });
+}
+
+}  // namespace mvldm
+
+extern "C" int mvldm_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, int n_img, int hw,
+                                   int c, int groups, float eps, int silu, int dtype, void* stats_ws,
+                                   mvldm_stream_t stream) {
+    return mvldm::groupnorm_run(x, y, gamma, beta, n_img, hw, c, groups, eps, silu, dtype, stats_ws, (hipStream_t)stream);
+}
+
+extern "C" int mvldm_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, int rows, int c,
+                                   float eps, int dtype, mvldm_stream_t stream) {
+    return mvldm::layernorm_run(x, y, gamma, beta, rows, c, eps, dtype, (hipStream_t)stream);
+}

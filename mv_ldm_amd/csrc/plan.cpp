@@ -1,0 +1,169 @@
+// Plan executor: a whole forward as a flat op list, run without touching Python, optionally captured
+// into a hipGraph (include/mvldm.h, "Plans").
+#include <vector>
+
+#include "common.h"
+
+namespace mvldm {
+int igemm_run(const mvldm_igemm_desc& d, hipStream_t s);
+int groupnorm_run(const void* x, void* y, const float* gamma, const float* beta, int n_img, int hw, int c, int groups,
+                  float eps, int silu, int dtype, void* stats_ws, hipStream_t s);
+int layernorm_run(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps, int dtype,
+                  hipStream_t s);
+int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,
+                  int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len, float scale, int dtype,
+                  hipStream_t s);
+int temb_run(const int64_t* ts, const float* freqs, void* out, int n, int dim, int flip, int dst_dtype, hipStream_t s);
+int eltwise_run(const void* x, void* y, size_t n, int op, int src_dtype, int dst_dtype, hipStream_t s);
+int ddim_run(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img, const int32_t* uncond_img,
+             int n_tgt, int hw, int c, float cfg_scale, const float* coef, const int32_t* step_ptr, void* unet_in,
+             int unet_in_c, int unet_in_dtype, hipStream_t s);
+int advance_run(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps, const int32_t* tgt_rows,
+                int n_rows, hipStream_t s);
+int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off, int dst_dtype, hipStream_t s);
+int to_nchw_run(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off, int src_dtype, float scale,
+                float shift, int clamp01, hipStream_t s);
+
+static int run_op(const mvldm_op& op, hipStream_t s) {
+    switch (op.kind) {
+        case MVLDM_OP_IGEMM: return igemm_run(op.u.igemm, s);
+        case MVLDM_OP_GROUPNORM: {
+            const auto& g = op.u.groupnorm;
+            return groupnorm_run(g.x, g.y, g.gamma, g.beta, g.n_img, g.hw, g.c, g.groups, g.eps, g.silu, g.dtype, g.stats_ws, s);
+        }
+        case MVLDM_OP_LAYERNORM: {
+            const auto& l = op.u.layernorm;
+            return layernorm_run(l.x, l.y, l.gamma, l.beta, l.rows, l.c, l.eps, l.dtype, s);
+        }
+        case MVLDM_OP_ATTENTION: {
+            const auto& a = op.u.attention;
+            return attention_run(a.q, a.k, a.v, a.out, a.ld_q, a.ld_k, a.ld_v, a.ld_o, a.heads, a.head_dim, a.seg, a.n_seg,
+                                 a.max_q_len, a.scale, a.dtype, s);
+        }
+        case MVLDM_OP_TIMESTEP_EMBED: {
+            const auto& t = op.u.temb;
+            return temb_run(t.timesteps, t.freqs, t.out, t.n, t.dim, t.flip, t.dst_dtype, s);
+        }
+        case MVLDM_OP_ELTWISE: {
+            const auto& e = op.u.eltwise;
+            return eltwise_run(e.x, e.y, e.n, e.op, e.src_dtype, e.dst_dtype, s);
+        }
+        case MVLDM_OP_DDIM_STEP: {
+            const auto& d = op.u.ddim;
+            return ddim_run(d.eps, d.x_t, d.x_next, d.cond_img, d.uncond_img, d.n_tgt, d.hw, d.c, d.cfg_scale, d.coef,
+                            d.step_ptr, d.unet_in, d.unet_in_c, d.unet_in_dtype, s);
+        }
+        case MVLDM_OP_DDIM_ADVANCE: {
+            const auto& a = op.u.advance;
+            return advance_run(a.step_ptr, a.t_table, a.n_steps, a.timesteps, a.tgt_rows, a.n_rows, s);
+        }
+        case MVLDM_OP_NCHW_TO_NHWC: {
+            const auto& l = op.u.layout;
+            return to_nhwc_run(reinterpret_cast<const float*>(l.src), l.dst, l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype, s);
+        }
+        case MVLDM_OP_NHWC_TO_NCHW: {
+            const auto& l = op.u.layout;
+            return to_nchw_run(l.src, reinterpret_cast<float*>(l.dst), l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype,
+                               l.scale, l.shift, l.clamp01, s);
+        }
+        case MVLDM_OP_MEMCPY: {
+            const auto& m = op.u.memcpy_;
+            if (m.bytes == 0) return MVLDM_OK;
+            MVLDM_CHECK_HIP(hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyDeviceToDevice, s));
+            return MVLDM_OK;
+        }
+        default: return set_error(MVLDM_ERR_ARG, "plan: unknown op kind %d", op.kind);
+    }
+}
+}  // namespace mvldm
+
+struct mvldm_plan {
+    std::vector<mvldm_op> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+using namespace mvldm;
+
+extern "C" int mvldm_plan_create(const mvldm_op* ops, int n_ops, mvldm_plan** out) {
+    MVLDM_REQUIRE(ops && out && n_ops >= 0, "plan_create: bad arguments");
+    mvldm_plan* p = new mvldm_plan();
+    p->ops.assign(ops, ops + n_ops);
+    *out = p;
+    return MVLDM_OK;
+}
+
+extern "C" int mvldm_plan_num_ops(const mvldm_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int mvldm_plan_run_range(mvldm_plan* p, int first, int last, mvldm_stream_t stream) {
+    MVLDM_REQUIRE(p && first >= 0 && last <= (int)p->ops.size() && first <= last, "plan_run_range: bad range");
+    for (int i = first; i < last; ++i) {
+        int rc = run_op(p->ops[i], (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return MVLDM_OK;
+}
+
+extern "C" int mvldm_plan_run(mvldm_plan* p, mvldm_stream_t stream) {
+    MVLDM_REQUIRE(p, "plan_run: null plan");
+    return mvldm_plan_run_range(p, 0, (int)p->ops.size(), stream);
+}
+
+extern "C" int mvldm_plan_capture(mvldm_plan* p, mvldm_stream_t stream) {
+    MVLDM_REQUIRE(p && stream, "plan_capture: needs a non-default stream");
+    hipStream_t s = (hipStream_t)stream;
+    if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+    if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+    // one eager pass first so that lazily-set function attributes are in place before capture
+    int rc = mvldm_plan_run(p, stream);
+    if (rc) return rc;
+    MVLDM_CHECK_HIP(hipStreamSynchronize(s));
+    MVLDM_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = mvldm_plan_run(p, stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return set_error(MVLDM_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    p->graph = g;
+    MVLDM_CHECK_HIP(hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0));
+    return MVLDM_OK;
+}
+
+extern "C" int mvldm_plan_replay(mvldm_plan* p, mvldm_stream_t stream) {
+    MVLDM_REQUIRE(p && p->exec, "plan_replay: plan was not captured");
+    MVLDM_CHECK_HIP(hipGraphLaunch(p->exec, (hipStream_t)stream));
+    return MVLDM_OK;
+}
+
+extern "C" int mvldm_plan_profile(mvldm_plan* p, mvldm_stream_t stream, int iters, float* per_op_ms) {
+    MVLDM_REQUIRE(p && per_op_ms && iters > 0, "plan_profile: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = (int)p->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) MVLDM_CHECK_HIP(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    int rc = MVLDM_OK;
+    for (int it = 0; it < iters && !rc; ++it) {
+        MVLDM_CHECK_HIP(hipEventRecord(ev[0], s));
+        for (int i = 0; i < n && !rc; ++i) {
+            rc = run_op(p->ops[i], s);
+            hipEventRecord(ev[i + 1], s);
+        }
+        MVLDM_CHECK_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < n && !rc; ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            acc[i] += ms;
+        }
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    for (int i = 0; i < n; ++i) per_op_ms[i] = (float)(acc[i] / iters);
+    return rc;
+}
+
+extern "C" void mvldm_plan_destroy(mvldm_plan* p) {
+    if (!p) return;
+    if (p->exec) hipGraphExecDestroy(p->exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    delete p;
+}

@@ -1,0 +1,248 @@
+"""Tensor-level wrappers over the C ABI (include/mvldm.h).  torch is plumbing here: device memory,
+the current HIP stream and dtype tags.  Every function enqueues hand-written HIP kernels from
+libmvldm_hip.so on `torch.cuda.current_stream()`; nothing falls back to torch math.
+
+Conventions: activations are NHWC tensors `[n_img, h, w, c]` (or token matrices `[rows, c]`) in the
+activation dtype; biases / norm parameters / statistics are fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+
+
+def dt(t) -> int:
+    return _DT[t if isinstance(t, torch.dtype) else t.dtype]
+
+
+def epc(dtype: torch.dtype) -> int:
+    """elements per 16-byte chunk: channel counts must be multiples of this"""
+    return 4 if dtype == torch.float32 else 8
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _roundup(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------------ workspaces
+_WS: dict = {}
+
+
+def workspace(nbytes: int, device, key: str = "splitk") -> torch.Tensor:
+    """grow-only scratch buffer per (device, key); eager ops share it (stream-ordered reuse)."""
+    k = (str(device), key)
+    cur = _WS.get(k)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[k] = cur
+    return cur
+
+
+# ------------------------------------------------------------------------------------------ weights
+@dataclass
+class PackedWeight:
+    """K-major [n_pad][k_pad] weight in the activation dtype + what the kernel needs to know."""
+    data: torch.Tensor
+    n_out: int
+    n_pad: int
+    k_pad: int
+    c_pad: int      # channels per tap as seen by the kernel (sum of source channels)
+    ksize: int
+    geglu: bool = False
+
+
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None, geglu: bool = False) -> PackedWeight:
+    """w: fp32 `[n_out, c_in, k, k]` (conv) or `[n_out, c_in]` (linear), on the GPU."""
+    assert w.is_cuda, "pack_weight needs a device tensor (no CPU path)"
+    w = w.detach().to(torch.float32).contiguous()
+    n_out, c_in = w.shape[0], w.shape[1]
+    ksize = w.shape[2] if w.ndim == 4 else 1
+    e = epc(dtype)
+    c_pad = _roundup(c_in, e) if c_pad is None else c_pad
+    bk = 32 if dtype == torch.float32 else 64
+    k_pad = _roundup(ksize * ksize * c_pad, bk)
+    n_pad = _roundup(n_out, 64)
+    out = torch.empty(n_pad, k_pad, dtype=dtype, device=w.device)
+    L.check(L.load().mvldm_pack_weight(w.data_ptr(), out.data_ptr(), n_out, c_in, ksize, c_pad, n_pad, k_pad,
+                                       int(geglu), dt(dtype), stream()))
+    return PackedWeight(out, n_out, n_pad, k_pad, c_pad, ksize, geglu)
+
+
+# ------------------------------------------------------------------------------------------ igemm
+def igemm_desc(src0, src1, pw: PackedWeight, dst, *, n_img, h_in, w_in, h_out, w_out, stride=1, pad=None, upsample=False,
+               bias=None, row_bias=None, residual=None, epilogue=L.EPI_NONE, out_scale=1.0, ws=None, splitk=0,
+               tile=0) -> L.IgemmDesc:
+    d = L.IgemmDesc()
+    c0 = src0.shape[-1]
+    c1 = 0 if src1 is None else src1.shape[-1]
+    assert c0 + c1 == pw.c_pad, f"weight packed for {pw.c_pad} channels, sources give {c0}+{c1}"
+    d.src0, d.src1, d.weight = ptr(src0), ptr(src1), ptr(pw.data)
+    d.bias, d.row_bias, d.residual, d.dst = ptr(bias), ptr(row_bias), ptr(residual), ptr(dst)
+    d.c0, d.c1 = c0, c1
+    d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n_img, h_in, w_in, h_out, w_out
+    d.ksize, d.stride, d.upsample = pw.ksize, stride, int(upsample)
+    d.pad = (pw.ksize // 2) if pad is None else pad
+    d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
+    d.row_bias_ld = 0 if row_bias is None else row_bias.stride(0)
+    d.epilogue, d.act_dtype, d.dst_dtype = epilogue, dt(src0), dt(dst)
+    d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
+    if ws is not None:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    else:
+        d.workspace, d.workspace_bytes = None, 0
+        if splitk == 0:
+            d.splitk = 1
+    return d
+
+
+def conv2d(x: torch.Tensor, pw: PackedWeight, bias=None, *, x2=None, stride=1, pad=None, upsample=False, row_bias=None,
+           residual=None, epilogue=L.EPI_NONE, out_dtype=None, out_scale=1.0, splitk=0, tile=0) -> torch.Tensor:
+    """x: NHWC `[n, h, w, c]`; x2: optional second source concatenated along c.  Returns NHWC."""
+    assert x.is_cuda and x.is_contiguous() and (x2 is None or x2.is_contiguous())
+    n, h, w, _ = x.shape
+    pad = (pw.ksize // 2) if pad is None else pad
+    hs, ws_ = (2 * h, 2 * w) if upsample else (h, w)
+    if pw.ksize == 3 and stride == 2 and pad == 0:       # VAE encoder: F.pad(0,1,0,1) then stride-2 conv
+        ho, wo = (hs + 1 - 3) // 2 + 1, (ws_ + 1 - 3) // 2 + 1
+    else:
+        ho, wo = (hs + 2 * pad - pw.ksize) // stride + 1, (ws_ + 2 * pad - pw.ksize) // stride + 1
+    n_dst = pw.n_out // 2 if epilogue == L.EPI_GEGLU else pw.n_out
+    out = torch.empty(n, ho, wo, n_dst, dtype=out_dtype or x.dtype, device=x.device)
+    scratch = None
+    if splitk != 1:
+        scratch = workspace(16 * n * ho * wo * pw.n_pad * 4, x.device)
+    d = igemm_desc(x, x2, pw, out, n_img=n, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, pad=pad,
+                   upsample=upsample, bias=bias, row_bias=row_bias, residual=residual, epilogue=epilogue,
+                   out_scale=out_scale, ws=scratch, splitk=splitk, tile=tile)
+    L.check(L.load().mvldm_igemm_fwd(C.byref(d), stream()))
+    return out
+
+
+def linear(x: torch.Tensor, pw: PackedWeight, bias=None, *, residual=None, epilogue=L.EPI_NONE, out_dtype=None,
+           splitk=0, tile=0) -> torch.Tensor:
+    """x: `[rows, c]` token matrix."""
+    rows, c = x.shape
+    y = conv2d(x.view(rows, 1, 1, c), pw, bias, residual=None if residual is None else residual.view(rows, 1, 1, -1),
+               epilogue=epilogue, out_dtype=out_dtype, splitk=splitk, tile=tile)
+    return y.view(rows, -1)
+
+
+# ------------------------------------------------------------------------------------------ norms
+def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool) -> torch.Tensor:
+    """x NHWC `[n, h, w, c]` (or `[n, hw, c]`)."""
+    assert x.is_cuda and x.is_contiguous()
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    ws = workspace(n * L.GN_MAX_CHUNKS * groups * 2 * 8, x.device, "gn")
+    L.check(L.load().mvldm_groupnorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, hw, c, groups,
+                                         eps, int(silu), dt(x), ws.data_ptr(), stream()))
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    assert x.is_cuda and x.is_contiguous()
+    c = x.shape[-1]
+    rows = x.numel() // c
+    y = torch.empty_like(x)
+    L.check(L.load().mvldm_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, c, eps,
+                                         dt(x), stream()))
+    return y
+
+
+# ------------------------------------------------------------------------------------------ attention
+def make_segments(q_lens, kv_lens=None, device="cuda") -> torch.Tensor:
+    """contiguous segments -> int32 [n_seg, 4] = {q_row0, q_len, kv_row0, kv_len}"""
+    kv_lens = q_lens if kv_lens is None else kv_lens
+    rows, q0, k0 = [], 0, 0
+    for ql, kl in zip(q_lens, kv_lens):
+        rows.append([q0, ql, k0, kl])
+        q0, k0 = q0 + ql, k0 + kl
+    return torch.tensor(rows, dtype=torch.int32, device=device)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, head_dim: int, seg: torch.Tensor,
+              max_q_len: int, scale: Optional[float] = None) -> torch.Tensor:
+    """q/k/v: 2-D row-major views `[tokens, >= heads*head_dim]` (may be column slices of one fused
+    projection: only the row stride is used).  Returns `[q_tokens, heads*head_dim]`."""
+    assert q.is_cuda and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    out = torch.empty(q.shape[0], heads * head_dim, dtype=q.dtype, device=q.device)
+    scale = head_dim ** -0.5 if scale is None else scale
+    L.check(L.load().mvldm_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
+                                         v.stride(0), out.stride(0), heads, head_dim, seg.data_ptr(), seg.shape[0],
+                                         max_q_len, scale, dt(q), stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ small ops
+def timestep_embed(timesteps: torch.Tensor, freqs: torch.Tensor, dim: int, flip_sin_to_cos: bool,
+                   dtype=torch.float32) -> torch.Tensor:
+    assert timesteps.dtype == torch.int64 and timesteps.is_cuda
+    out = torch.empty(timesteps.numel(), dim, dtype=dtype, device=timesteps.device)
+    L.check(L.load().mvldm_timestep_embed_fwd(timesteps.data_ptr(), freqs.data_ptr(), out.data_ptr(), timesteps.numel(),
+                                              dim, int(flip_sin_to_cos), dt(dtype), stream()))
+    return out
+
+
+def eltwise(x: torch.Tensor, op: int, out_dtype=None) -> torch.Tensor:
+    assert x.is_cuda and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    L.check(L.load().mvldm_eltwise_fwd(x.data_ptr(), y.data_ptr(), x.numel(), op, dt(x), dt(y), stream()))
+    return y
+
+
+def silu(x, out_dtype=None):
+    return eltwise(x, L.ELT_SILU, out_dtype)
+
+
+def convert(x, out_dtype):
+    return eltwise(x, L.ELT_COPY, out_dtype)
+
+
+def nchw_to_nhwc(src: torch.Tensor, dtype, dst: Optional[torch.Tensor] = None, c_off: int = 0,
+                 dst_c: Optional[int] = None) -> torch.Tensor:
+    """fp32 NCHW `[n, c, h, w]` -> NHWC `[n, h, w, dst_c]` (channels [c_off, c_off+c) written)."""
+    assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()
+    n, c, h, w = src.shape
+    if dst is None:
+        dst_c = c if dst_c is None else dst_c
+        dst = torch.zeros(n, h, w, dst_c, dtype=dtype, device=src.device)
+    L.check(L.load().mvldm_nchw_to_nhwc(src.data_ptr(), dst.data_ptr(), n, c, h * w, dst.shape[-1], c_off, dt(dst), stream()))
+    return dst
+
+
+def nhwc_to_nchw(src: torch.Tensor, c: Optional[int] = None, c_off: int = 0, scale=1.0, shift=0.0,
+                 clamp01=False) -> torch.Tensor:
+    assert src.is_cuda and src.is_contiguous()
+    n, h, w, sc = src.shape
+    c = sc if c is None else c
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=src.device)
+    L.check(L.load().mvldm_nhwc_to_nchw(src.data_ptr(), out.data_ptr(), n, c, h * w, sc, c_off, dt(src), scale, shift,
+                                        int(clamp01), stream()))
+    return out
+
+
+def ddim_cfg_step(eps, x_t, cond_img, uncond_img, cfg_scale, coef, step_ptr, unet_in=None) -> torch.Tensor:
+    """eps: fp32 NHWC `[n_img, h, w, c]`; x_t: fp32 NHWC `[n_tgt, h, w, c]` -> x_{t-1} (same shape)."""
+    n_tgt, h, w, c = x_t.shape
+    out = torch.empty_like(x_t)
+    L.check(L.load().mvldm_ddim_cfg_step(eps.data_ptr(), x_t.data_ptr(), out.data_ptr(), cond_img.data_ptr(), ptr(uncond_img),
+                                         n_tgt, h * w, c, cfg_scale, coef.data_ptr(), step_ptr.data_ptr(), ptr(unet_in),
+                                         0 if unet_in is None else unet_in.shape[-1],
+                                         dt(unet_in) if unet_in is not None else L.F32, stream()))
+    return out

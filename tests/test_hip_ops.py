@@ -1,0 +1,318 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (mv_ldm_amd.ops -> libmvldm_hip.so).
+
+Reference = the same op evaluated by plain torch on the CPU in fp64 from the SAME (already
+dtype-rounded) inputs, so the only difference left is the kernel's own accumulation order and the
+rounding of its output.  Tolerances (relative L2 / worst element relative to the output's RMS):
+    f32 : 2e-5 / 2e-4     (fp32 MFMA accumulation over K up to ~3e3)
+    f16 : 1e-3 / 1e-2     (output rounding 2^-11, P rounded to f16 in attention)
+    bf16: 6e-3 / 5e-2     (output rounding 2^-8,  P rounded to bf16 in attention)
+DDIM / scheduler arithmetic and all index work are bit-exact (asserted with torch.equal).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: (2e-5, 2e-4), torch.float16: (1e-3, 1e-2), torch.bfloat16: (6e-3, 5e-2)}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mv_ldm_amd import ops as O
+    from mv_ldm_amd import _lib as L
+    L.load()
+    return O
+
+
+def G(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rnd(shape, seed, dtype, scale=1.0):
+    """fp32 values already representable in `dtype`"""
+    return (torch.randn(shape, generator=G(seed)) * scale).to(dtype).float()
+
+
+def close(got, ref, dtype, what=""):
+    got, ref = got.detach().double().cpu(), ref.double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    rl2, rmax = TOL[dtype]
+    rms = ref.pow(2).mean().sqrt().clamp_min(1e-30)
+    e2 = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+    emax = float((got - ref).abs().max() / rms)
+    assert e2 <= rl2 and emax <= rmax, f"{what}: rel-L2 {e2:.3e} (tol {rl2}), max/rms {emax:.3e} (tol {rmax})"
+
+
+def nhwc(x, dtype):  # NCHW fp32 cpu -> NHWC dtype cuda
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def nchw(y):  # NHWC cuda -> NCHW fp64 cpu
+    return y.float().cpu().permute(0, 3, 1, 2).double()
+
+
+# ------------------------------------------------------------------------------------------------ igemm
+CONV_CASES = [
+    # name, n, cin, cin2, cout, h, w, k, stride, pad, upsample
+    ("3x3", 2, 64, 0, 96, 8, 8, 3, 1, 1, False),
+    ("3x3_wide_odd", 3, 40, 0, 72, 5, 7, 3, 1, 1, False),
+    ("3x3_concat", 2, 64, 32, 64, 8, 8, 3, 1, 1, False),
+    ("3x3_stride2", 2, 64, 0, 64, 8, 8, 3, 2, 1, False),
+    ("3x3_stride2_asym_vae", 1, 32, 0, 32, 8, 8, 3, 2, 0, False),
+    ("3x3_upsample", 2, 64, 0, 64, 4, 4, 3, 1, 1, True),
+    ("1x1_shortcut", 2, 96, 0, 64, 6, 6, 1, 1, 0, False),
+    ("3x3_big", 1, 320, 0, 320, 16, 16, 3, 1, 1, False),
+    ("3x3_lowres_wide", 3, 1280, 1280, 1280, 4, 4, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_variants(ops, case, dtype):
+    name, n, cin, cin2, cout, h, w, k, stride, pad, up = case
+    if dtype != torch.bfloat16 and name in ("3x3_lowres_wide",):
+        pytest.skip("large case on the throughput dtype only")
+    ws = 1.0 / math.sqrt((cin + cin2) * k * k)
+    x = rnd((n, cin, h, w), 1, dtype)
+    x2 = rnd((n, cin2, h, w), 2, dtype) if cin2 else None
+    wt = rnd((cout, cin + cin2, k, k), 3, dtype, ws)
+    b = torch.randn(cout, generator=G(4)) * 0.1
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    xr = xin.double()
+    if up:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    if k == 3 and stride == 2 and pad == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    ref = F.conv2d(xr, wt.double(), b.double(), stride=stride, padding=pad)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=None if x2 is None else nhwc(x2, dtype), stride=stride, pad=pad, upsample=up)
+    close(nchw(y), ref, dtype, name)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_conv_tiles_and_splitk(ops, dtype):
+    """every tile configuration and split-K depth gives the same result"""
+    n, cin, cout, h = 2, 128, 192, 12
+    x, wt = rnd((n, cin, h, h), 5, dtype), rnd((cout, cin, 3, 3), 6, dtype, 1 / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=G(7)) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    xg = nhwc(x, dtype)
+    for tile in (1, 2, 3, 4, 5):
+        for sk in (1, 2, 5):
+            y = ops.conv2d(xg, pw, b.cuda(), tile=tile, splitk=sk)
+            close(nchw(y), ref, dtype, f"tile{tile}/splitk{sk}")
+    close(nchw(ops.conv2d(xg, pw, b.cuda())), ref, dtype, "auto")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_conv_epilogues(ops, dtype):
+    """+bias +per-image bias (time embedding) +residual, SiLU, fp32 output, out_scale"""
+    n, cin, cout, h = 3, 64, 96, 6
+    x, wt = rnd((n, cin, h, h), 8, dtype), rnd((cout, cin, 3, 3), 9, dtype, 1 / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=G(10)) * 0.1
+    rb = torch.randn(n, cout, generator=G(11))
+    res = rnd((n, cout, h, h), 12, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    base = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), row_bias=rb.cuda(), residual=nhwc(res, dtype))
+    close(nchw(y), base + rb.double()[:, :, None, None] + res.double(), dtype, "temb+residual")
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), epilogue=1, out_dtype=torch.float32, out_scale=0.5)
+    assert y.dtype == torch.float32
+    close(nchw(y), F.silu(base) * 0.5, dtype, "silu/f32/scale")
+    for sk in (2, 3):  # same epilogues through the split-K reduce kernel
+        y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), row_bias=rb.cuda(), residual=nhwc(res, dtype), splitk=sk)
+        close(nchw(y), base + rb.double()[:, :, None, None] + res.double(), dtype, f"temb+residual splitk{sk}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_conv_in_out_channel_padding(ops, dtype):
+    """conv_in: 11 real channels in a 16-channel NHWC buffer; conv_out: 4 output channels"""
+    n, h = 2, 8
+    x = rnd((n, 11, h, h), 13, dtype)
+    w_in = rnd((64, 11, 3, 3), 14, dtype, 0.1)
+    pw = ops.pack_weight(w_in.cuda(), dtype, c_pad=16)
+    xp = torch.zeros(n, h, h, 16, dtype=dtype, device="cuda")
+    xp[..., :11] = nhwc(x, dtype)
+    close(nchw(ops.conv2d(xp, pw)), F.conv2d(x.double(), w_in.double(), padding=1), dtype, "conv_in")
+    x2 = rnd((n, 64, h, h), 15, dtype)
+    w_out = rnd((4, 64, 3, 3), 16, dtype, 0.05)
+    pw2 = ops.pack_weight(w_out.cuda(), dtype)
+    y = ops.conv2d(nhwc(x2, dtype), pw2, out_dtype=torch.float32)
+    assert y.shape == (n, h, h, 4)
+    close(nchw(y), F.conv2d(x2.double(), w_out.double(), padding=1), dtype, "conv_out")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("rows,cin,cout", [(9, 1280, 320), (80, 320, 960), (300, 64, 64), (1000, 640, 640)])
+def test_linear(ops, dtype, rows, cin, cout):
+    x, wt = rnd((rows, cin), 17, dtype), rnd((cout, cin), 18, dtype, 1 / math.sqrt(cin))
+    b = torch.randn(cout, generator=G(19)) * 0.1
+    res = rnd((rows, cout), 20, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), residual=res.to(dtype).cuda())
+    close(y.float().cpu().double(), F.linear(x.double(), wt.double(), b.double()) + res.double(), dtype, "linear")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("rows,c", [(50, 64), (300, 320)])
+def test_geglu(ops, dtype, rows, c):
+    x, wt = rnd((rows, c), 21, dtype), rnd((8 * c, c), 22, dtype, 1 / math.sqrt(c))
+    b = torch.randn(8 * c, generator=G(23)) * 0.1
+    pw = ops.pack_weight(wt.cuda(), dtype, geglu=True)
+    hgate = F.linear(x.double(), wt.double(), b.double())
+    a, g = hgate.chunk(2, -1)
+    ref = a * F.gelu(g)
+    for sk in (1, 2):
+        y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, splitk=sk)
+        assert y.shape == (rows, 4 * c)
+        close(y.float().cpu().double(), ref, dtype, f"geglu splitk{sk}")
+
+
+def test_pack_weight_layout(ops):
+    w = torch.randn(70, 24, 3, 3, generator=G(24))
+    pw = ops.pack_weight(w.cuda(), torch.float32)
+    ref = torch.zeros(pw.n_pad, pw.k_pad)
+    ref[:70, :9 * 24] = w.permute(0, 2, 3, 1).reshape(70, -1)
+    assert torch.equal(pw.data.cpu(), ref)
+    wl = torch.randn(128, 16, generator=G(25))
+    pg = ops.pack_weight(wl.cuda(), torch.float32, geglu=True).data.cpu()
+    assert torch.equal(pg[0:32, :16], wl[0:32]) and torch.equal(pg[32:64, :16], wl[64:96])
+    assert torch.equal(pg[64:96, :16], wl[32:64]) and torch.equal(pg[96:128, :16], wl[96:128])
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("n,c,h,w,silu", [(2, 32, 4, 4, True), (3, 64, 8, 8, False), (5, 320, 32, 32, True),
+                                          (2, 2560, 4, 4, True), (1, 128, 64, 48, True), (2, 960, 16, 16, False)])
+def test_groupnorm(ops, dtype, n, c, h, w, silu):
+    x = rnd((n, c, h, w), 26, dtype) * 2 + 0.7
+    x = x.to(dtype).float()
+    gm, bt = 1 + 0.2 * torch.randn(c, generator=G(27)), 0.2 * torch.randn(c, generator=G(28))
+    ref = F.group_norm(x.double(), 32, gm.double(), bt.double(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    y = ops.groupnorm(nhwc(x, dtype), gm.cuda(), bt.cuda(), 32, 1e-5, silu)
+    close(nchw(y), ref, dtype, "groupnorm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("rows,c", [(7, 64), (1024, 320), (80, 1280), (33, 2560)])
+def test_layernorm(ops, dtype, rows, c):
+    x = (rnd((rows, c), 29, dtype) * 1.5 + 0.3).to(dtype).float()
+    gm, bt = 1 + 0.2 * torch.randn(c, generator=G(30)), 0.2 * torch.randn(c, generator=G(31))
+    y = ops.layernorm(x.to(dtype).cuda(), gm.cuda(), bt.cuda(), 1e-5)
+    close(y.float().cpu().double(), F.layer_norm(x.double(), (c,), gm.double(), bt.double(), 1e-5), dtype, "layernorm")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, heads, d, q_lens, kv_lens):
+    outs, q0, k0 = [], 0, 0
+    for ql, kl in zip(q_lens, kv_lens):
+        qq = q[q0:q0 + ql].double().view(ql, heads, d).transpose(0, 1)
+        kk = k[k0:k0 + kl].double().view(kl, heads, d).transpose(0, 1)
+        vv = v[k0:k0 + kl].double().view(kl, heads, d).transpose(0, 1)
+        sim = (qq @ kk.transpose(1, 2)) * d ** -0.5
+        outs.append((sim.softmax(-1) @ vv).transpose(0, 1).reshape(ql, heads * d))
+        q0, k0 = q0 + ql, k0 + kl
+    return torch.cat(outs)
+
+
+ATTN_CASES = [  # heads, d, q_lens (kv = q: self-attention)
+    (2, 8, [5]), (2, 16, [64, 64]), (3, 32, [100]), (8, 40, [320, 256]), (5, 64, [17, 256, 1]),
+    (8, 80, [1280]), (8, 160, [320, 80]), (8, 40, [1029]), (1, 64, [129, 127, 128]),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("heads,d,lens", ATTN_CASES, ids=[f"h{c[0]}d{c[1]}L{'_'.join(map(str, c[2]))}" for c in ATTN_CASES])
+def test_attention_self(ops, dtype, heads, d, lens):
+    n, C = sum(lens), heads * d
+    qkv = rnd((n, 3 * C), 32, dtype)           # one fused projection buffer: q|k|v column slices
+    ref = ref_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads, d, lens, lens)
+    g = qkv.to(dtype).cuda()
+    seg = ops.make_segments(lens)
+    y = ops.attention(g[:, :C], g[:, C:2 * C], g[:, 2 * C:], heads, d, seg, max(lens))
+    close(y.float().cpu().double(), ref, dtype, "attention")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_attention_cross_and_spike(ops, dtype):
+    """kv length != q length, and a key that dominates one query row late in the sequence (forces
+    the online-softmax rescale branch with a large max jump)."""
+    heads, d, ql, kl = 4, 40, [70, 33], [200, 1]
+    q, k, v = rnd((sum(ql), heads * d), 33, dtype), rnd((sum(kl), heads * d), 34, dtype), rnd((sum(kl), heads * d), 35, dtype)
+    k[150] = q[5] * 6.0   # large logit at key 150 (third tile) for query 5
+    k = k.to(dtype).float()
+    ref = ref_attention(q, k, v, heads, d, ql, kl)
+    seg = ops.make_segments(ql, kl)
+    y = ops.attention(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), heads, d, seg, max(ql))
+    close(y.float().cpu().double(), ref, dtype, "attention cross/spike")
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+def test_timestep_embedding_matches_oracle(ops):
+    from oracle.blocks import Timesteps
+    t = torch.tensor([0, 1, 20, 333, 980, 999], dtype=torch.int64)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    y = ops.timestep_embed(t.cuda(), freqs.cuda(), 320, True)
+    ref = Timesteps(320)(t)
+    assert (y.cpu() - ref).abs().max() < 2e-6      # sinf/cosf of an identical fp32 argument
+    y16 = ops.timestep_embed(t.cuda(), freqs.cuda(), 320, True, dtype=torch.bfloat16)
+    assert (y16.float().cpu() - ref).abs().max() < 4e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
+def test_eltwise_and_layout(ops, dtype):
+    x = rnd((3, 1280), 36, dtype)
+    close(ops.silu(x.to(dtype).cuda()).float().cpu().double(), F.silu(x.double()), dtype, "silu")
+    assert torch.equal(ops.convert(x.cuda(), dtype).cpu(), x.to(dtype))
+    img = torch.randn(2, 5, 4, 6, generator=G(37))
+    buf = torch.zeros(2, 4, 6, 16, dtype=dtype, device="cuda")
+    ops.nchw_to_nhwc(img.cuda(), dtype, dst=buf, c_off=3)
+    assert torch.equal(buf[..., 3:8].cpu(), img.permute(0, 2, 3, 1).to(dtype))
+    assert float(buf[..., :3].abs().max()) == 0 and float(buf[..., 8:].abs().max()) == 0
+    back = ops.nhwc_to_nchw(buf, c=5, c_off=3)
+    assert torch.equal(back.cpu(), img.to(dtype).float())
+    clamped = ops.nhwc_to_nchw(buf, c=5, c_off=3, scale=0.5, shift=0.5, clamp01=True)
+    assert torch.equal(clamped.cpu(), (img.to(dtype).float() * 0.5 + 0.5).clamp(0, 1))
+
+
+def test_ddim_cfg_step_bit_exact(ops):
+    """CFG compose + DDIM update: bit-identical to the torch CPU fp32 expression of the oracle
+    scheduler (diffusion_wrapper.py:444,451 / DDIMScheduler.step), every step of a 50-step run."""
+    from oracle.scheduler import DDIMScheduler
+    s = DDIMScheduler(clip_sample=False)
+    s.set_timesteps(50)
+    ac = s.alphas_cumprod
+    coef = []
+    for t in s.timesteps.tolist():
+        a_t = ac[t]
+        a_p = ac[t - 20] if t - 20 >= 0 else s.final_alpha_cumprod
+        coef.append(torch.stack([(1 - a_t) ** 0.5, a_t ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5]))
+    coef = torch.stack(coef).float().contiguous()
+    n_tgt, n_img, h, w, c = 3, 7, 4, 4, 4
+    g = G(38)
+    eps = torch.randn(n_img, h, w, c, generator=g)
+    x = torch.randn(n_tgt, h, w, c, generator=g)
+    cond = torch.tensor([1, 2, 3], dtype=torch.int32)
+    unc = torch.tensor([4, 5, 6], dtype=torch.int32)
+    unet_in = torch.zeros(n_img, h, w, 16, dtype=torch.bfloat16, device="cuda")
+    for step in (0, 1, 25, 49):
+        sp = torch.tensor([step], dtype=torch.int32).cuda()
+        t = s.timesteps[step]
+        pred = eps[unc.long()] + 3.0 * (eps[cond.long()] - eps[unc.long()])
+        ref = s.step(pred, t, x).prev_sample
+        got = ops.ddim_cfg_step(eps.cuda(), x.cuda(), cond.cuda(), unc.cuda(), 3.0, coef.cuda(), sp, unet_in)
+        assert torch.equal(got.cpu(), ref), f"step {step}"
+        assert torch.equal(unet_in[1:4, ..., :4].cpu(), ref.to(torch.bfloat16))
+        assert torch.equal(unet_in[4:7, ..., :4].cpu(), ref.to(torch.bfloat16))
+        ref_nocfg = s.step(eps[cond.long()], t, x).prev_sample
+        got = ops.ddim_cfg_step(eps.cuda(), x.cuda(), cond.cuda(), None, 3.0, coef.cuda(), sp, None)
+        assert torch.equal(got.cpu(), ref_nocfg)
