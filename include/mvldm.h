@@ -74,6 +74,7 @@ typedef struct mvldm_igemm_desc {
     int32_t dst_dtype;  /* act_dtype or MVLDM_F32 */
     int32_t splitk;     /* >= 1; 0 = let the library choose (needs workspace) */
     int32_t tile;       /* 0 = auto; else force a tile config (tests / tuning) */
+    int32_t dst_ld;     /* row stride of dst in elements; 0 = n_dst (dense).  > n_dst writes into a wider buffer */
     float out_scale;
     size_t workspace_bytes;
 } mvldm_igemm_desc;
@@ -92,11 +93,15 @@ int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksiz
  * GroupNorm (+ optional SiLU), NHWC.   replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D
  * (norm1/norm2 + nonlinearity), conv_norm_out + conv_act (mvunet.py:203-204), Transformer2DModel.norm
  * and SpatialTransformer3D.norm (mvdream/attention.py:96-97,423).  Statistics in fp64.
+ * The input may be the channel concatenation of two tensors x0 [.., c0] | x1 [.., c1] (x1 NULL, c1 0
+ * otherwise): the up-path skip concat (mvunet.py:176) feeds norm1 directly and is never materialised;
+ * groups are taken over the concatenated c0+c1 channels and y is [n_img][hw][c0+c1].
  * stats_ws: >= n_img * MVLDM_GN_MAX_CHUNKS * groups * 2 doubles.
  */
 #define MVLDM_GN_MAX_CHUNKS 32
-int mvldm_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, int n_img, int hw, int c,
-                        int groups, float eps, int silu, int dtype, void* stats_ws, mvldm_stream_t stream);
+int mvldm_groupnorm_fwd(const void* x0, const void* x1, void* y, const float* gamma, const float* beta, int n_img,
+                        int hw, int c0, int c1, int groups, float eps, int silu, int dtype, void* stats_ws,
+                        mvldm_stream_t stream);
 
 /* LayerNorm over the last dim of [rows][c].  replaces torch.nn.LayerNorm in BasicTransformerBlock
  * (diffusers) and BasicTransformerBlock3D norm1-3 (mvdream/attention.py:286-288,363-367). */
@@ -181,8 +186,8 @@ typedef struct mvldm_op {
     int32_t tag; /* caller-defined label (layer id) echoed by the profiler */
     union {
         mvldm_igemm_desc igemm;
-        struct { const void* x; void* y; const float* gamma; const float* beta; void* stats_ws;
-                 int32_t n_img, hw, c, groups, silu, dtype; float eps; } groupnorm;
+        struct { const void* x; const void* x1; void* y; const float* gamma; const float* beta; void* stats_ws;
+                 int32_t n_img, hw, c0, c1, groups, silu, dtype; float eps; } groupnorm;
         struct { const void* x; void* y; const float* gamma; const float* beta;
                  int32_t rows, c, dtype; float eps; } layernorm;
         struct { const void* q; const void* k; const void* v; void* out; const int32_t* seg;
@@ -202,6 +207,7 @@ typedef struct mvldm_op {
 } mvldm_op;
 
 typedef struct mvldm_plan mvldm_plan;
+int mvldm_op_run(const mvldm_op* op, mvldm_stream_t stream);                   /* one op, eagerly */
 int mvldm_plan_create(const mvldm_op* ops, int n_ops, mvldm_plan** out);      /* ops: host array, copied */
 int mvldm_plan_num_ops(const mvldm_plan* p);
 int mvldm_plan_run(mvldm_plan* p, mvldm_stream_t stream);                      /* eager launches */

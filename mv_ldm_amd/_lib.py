@@ -30,12 +30,13 @@ class IgemmDesc(C.Structure):
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
                 ("n_out", i32), ("n_pad", i32), ("k_pad", i32),
                 ("row_bias_ld", i32), ("epilogue", i32), ("act_dtype", i32), ("dst_dtype", i32),
-                ("splitk", i32), ("tile", i32), ("out_scale", f32), ("workspace_bytes", sz)]
+                ("splitk", i32), ("tile", i32), ("dst_ld", i32), ("out_scale", f32), ("workspace_bytes", sz)]
 
 
 class _GroupNorm(C.Structure):
-    _fields_ = [("x", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("stats_ws", vp),
-                ("n_img", i32), ("hw", i32), ("c", i32), ("groups", i32), ("silu", i32), ("dtype", i32), ("eps", f32)]
+    _fields_ = [("x", vp), ("x1", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("stats_ws", vp),
+                ("n_img", i32), ("hw", i32), ("c0", i32), ("c1", i32), ("groups", i32), ("silu", i32), ("dtype", i32),
+                ("eps", f32)]
 
 
 class _LayerNorm(C.Structure):
@@ -93,7 +94,7 @@ SIGNATURES = {
     "mvldm_igemm_fwd": (C.c_int, [C.POINTER(IgemmDesc), vp]),
     "mvldm_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
     "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 8 + [vp]),
-    "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp]),
+    "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp]),
     "mvldm_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
     "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp]),
     "mvldm_timestep_embed_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "mvldm_ddim_advance": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     "mvldm_nhwc_to_nchw": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, C.c_int, vp]),
+    "mvldm_op_run": (C.c_int, [C.POINTER(Op), vp]),
     "mvldm_plan_create": (C.c_int, [C.POINTER(Op), C.c_int, C.POINTER(vp)]),
     "mvldm_plan_num_ops": (C.c_int, [vp]),
     "mvldm_plan_run": (C.c_int, [vp, vp]),

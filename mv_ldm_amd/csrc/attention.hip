@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 
     // ---- normalise and write O[q][d] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (!q_ok) return;
     T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local) * p.ld_o + head * d;
 #pragma unroll
@@ -241,6 +241,85 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                 }
             }
         }
+}
+
+
+// ---- wide-head fallback (head_dim > 160: the VAE mid-block's single 512-wide head) ----------------
+// One wave per query row; the head dimension is spread over the 64 lanes (16-byte chunks), keys are
+// streamed from L2 two at a time, dot products are wave-reduced, online softmax in fp32.  VALU only:
+// this path carries < 0.1 % of the FLOPs of a sample and is kept simple.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void attention_wide_kernel(const AttnParams p) {
+    constexpr int EPC = Elt<T>::EPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int head = blockIdx.y;
+    const int4 sg = reinterpret_cast<const int4*>(p.seg)[blockIdx.z];
+    const int q_row0 = sg.x, q_len = sg.y, kv_row0 = sg.z, kv_len = sg.w;
+    const int q_local = blockIdx.x * 4 + wave;
+    if (q_local >= q_len) return;
+    const int d = p.d, nch = d / EPC;
+    const T* qp = reinterpret_cast<const T*>(p.q) + (size_t)(q_row0 + q_local) * p.ld_q + head * d;
+    float qv[NCH][EPC], ov[NCH][EPC];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        Chunk<T> c;
+        if (ch < nch) c = load_chunk<T>(qp + ch * EPC); else c.zero();
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) { qv[j][i] = c.get(i) * p.scale_log2e; ov[j][i] = 0.f; }
+    }
+    const T* kb = reinterpret_cast<const T*>(p.k) + (size_t)kv_row0 * p.ld_k + head * d;
+    const T* vb = reinterpret_cast<const T*>(p.v) + (size_t)kv_row0 * p.ld_v + head * d;
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int key = 0; key < kv_len; ++key) {
+        float part = 0.f;
+        Chunk<T> vc[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            Chunk<T> kc;
+            if (ch < nch) {
+                kc = load_chunk<T>(kb + (size_t)key * p.ld_k + ch * EPC);
+                vc[j] = load_chunk<T>(vb + (size_t)key * p.ld_v + ch * EPC);
+            } else {
+                kc.zero();
+                vc[j].zero();
+            }
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) part += qv[j][i] * kc.get(i);
+        }
+        const float sv = wave_sum(part);
+        const float m_new = fmaxf(m_run, sv);
+        const float alpha = exp2f(m_run - m_new), pv = exp2f(sv - m_new);
+        m_run = m_new;
+        l_run = l_run * alpha + pv;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) ov[j][i] = ov[j][i] * alpha + pv * vc[j].get(i);
+    }
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local) * p.ld_o + head * d;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nch) {
+            Chunk<T> c;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) c.set(i, ov[j][i] * inv);
+            store_chunk<T>(op + ch * EPC, c);
+        }
+    }
+}
+
+template <typename T> static int launch_attn_wide(const AttnParams& p, int n_seg, int max_q_len, hipStream_t s) {
+    const int nch = p.d / Elt<T>::EPC;
+    dim3 grid((max_q_len + 3) / 4, p.heads, n_seg);
+    if (nch <= 64) hipLaunchKernelGGL((attention_wide_kernel<T, 1>), grid, dim3(256), 0, s, p);
+    else if (nch <= 128) hipLaunchKernelGGL((attention_wide_kernel<T, 2>), grid, dim3(256), 0, s, p);
+    else if (nch <= 256) hipLaunchKernelGGL((attention_wide_kernel<T, 4>), grid, dim3(256), 0, s, p);
+    else return set_error(MVLDM_ERR_UNSUPPORTED, "attention: head_dim %d too wide", p.d);
+    return check_launch();
 }
 
 template <typename T, int DP> static int launch_attn(const AttnParams& p, int n_seg, int max_q_len, hipStream_t s) {
@@ -267,14 +346,14 @@ int attention_run(const void* q, const void* k, const void* v, void* out, int ld
                   hipStream_t s) {
     MVLDM_REQUIRE(q && k && v && out && seg, "attention: null pointer");
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
-    MVLDM_REQUIRE(head_dim > 0 && head_dim % epc == 0 && head_dim <= 160,
-                  "attention: head_dim %d unsupported (multiple of %d, <= 160)", head_dim, epc);
+    MVLDM_REQUIRE(head_dim > 0 && head_dim % epc == 0, "attention: head_dim %d must be a multiple of %d", head_dim, epc);
     MVLDM_REQUIRE(ld_q % epc == 0 && ld_k % epc == 0 && ld_v % epc == 0 && ld_o % 4 == 0, "attention: row strides must keep 16-byte alignment");
     if (n_seg == 0 || max_q_len == 0) return MVLDM_OK;
     AttnParams p{q, k, v, out, seg, ld_q, ld_k, ld_v, ld_o, heads, head_dim, scale * 1.4426950408889634f};
     const int dp = (head_dim + 15) / 16 * 16;
     return dispatch_dtype(dtype, [&](auto t) {
         using T = decltype(t);
+        if (head_dim > 160) return launch_attn_wide<T>(p, n_seg, max_q_len, s);
         switch (dp) {
             case 16: return launch_attn<T, 16>(p, n_seg, max_q_len, s);
             case 32: return launch_attn<T, 32>(p, n_seg, max_q_len, s);

@@ -27,7 +27,7 @@ struct IgemmParams {
     int n_img, h_in, w_in, h_out, w_out, hw_out;
     int ksize, stride, pad, upsample;
     int M, n_out, n_pad, n_dst, k_pad, taps;
-    int row_bias_ld, epilogue, dst_f32;
+    int row_bias_ld, epilogue, dst_f32, dst_ld;
     float out_scale;
     int splitk, k_tiles, k_tiles_per_split;
     int tiles_m, tiles_n;
@@ -87,8 +87,8 @@ template <typename T>
 __device__ __forceinline__ void epilogue_store(const IgemmParams& p, int m, int n_dst_col, float v) {
     // v already includes bias/row_bias/activation
     v *= p.out_scale;
-    const size_t o = (size_t)m * p.n_dst + n_dst_col;
-    if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[o]);
+    if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[(size_t)m * p.n_dst + n_dst_col]);
+    const size_t o = (size_t)m * p.dst_ld + n_dst_col;
     if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
     else reinterpret_cast<T*>(p.dst)[o] = from_f32<T>(v);
 }
@@ -398,6 +398,8 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
     p.row_bias_ld = d.row_bias_ld; p.epilogue = d.epilogue; p.dst_f32 = d.dst_dtype == MVLDM_F32;
     p.out_scale = d.out_scale;
+    p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
+    MVLDM_REQUIRE(p.dst_ld >= p.n_dst, "igemm: dst_ld %d < n_dst %d", p.dst_ld, p.n_dst);
     p.k_tiles = d.k_pad / bk;
     tile = d.tile;
     int splitk = d.splitk;

@@ -16,8 +16,9 @@ namespace mvldm {
 
 // ---------------------------------------------------------------------------------------------- GN
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ partial, int hw,
-                                                       int c, int groups, int rows_per_chunk, int nchunk) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
+                                                       double* __restrict__ partial, int hw, int c, int groups,
+                                                       int rows_per_chunk, int nchunk) {
     constexpr int EPC = Elt<T>::EPC;
     __shared__ double s_sum[64], s_sq[64];  // groups <= 64
     const int img = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
@@ -38,9 +39,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < EPC; ++i) { s[i] = 0.0; q[i] = 0.0; }
         if (rl < R) {
-            const T* base = x + ((size_t)img * hw) * c + (size_t)cc * EPC;
+            const int ch0 = cc * EPC;
+            const bool first = ch0 < c0;
+            const int cs = first ? c0 : c - c0;
+            const T* base = (first ? x0 + ch0 : x1 + (ch0 - c0)) + ((size_t)img * hw) * cs;
             for (int r = r_begin + rl; r < r_end; r += R) {
-                const Chunk<T> v = load_chunk<T>(base + (size_t)r * c);
+                const Chunk<T> v = load_chunk<T>(base + (size_t)r * cs);
 #pragma unroll
                 for (int i = 0; i < EPC; ++i) {
                     const double f = (double)v.get(i);
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
+                                                       T* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const double* __restrict__ partial, int hw, int c, int groups,
                                                        int rows_per_chunk, int nchunk, float eps, int silu) {
@@ -103,11 +108,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int ncc = c / EPC;
     const int r_begin = chunk * rows_per_chunk, r_end = min(hw, r_begin + rows_per_chunk);
     const size_t total = (size_t)(r_end - r_begin) * ncc;
-    const T* xb = x + ((size_t)img * hw + r_begin) * c;
-    T* yb = y + ((size_t)img * hw + r_begin) * c;
+    const size_t row0 = (size_t)img * hw + r_begin;
+    T* yb = y + row0 * c;
+    const int c1 = c - c0;
     for (size_t idx = tid; idx < total; idx += blockDim.x) {
         const int cc = (int)(idx % ncc);
-        const Chunk<T> v = load_chunk<T>(xb + idx * EPC);
+        const size_t r = idx / ncc;
+        const int ch0 = cc * EPC;
+        const Chunk<T> v = ch0 < c0 ? load_chunk<T>(x0 + (row0 + r) * c0 + ch0)
+                                    : load_chunk<T>(x1 + (row0 + r) * c1 + (ch0 - c0));
         Chunk<T> o;
 #pragma unroll
         for (int i = 0; i < EPC; ++i) {
@@ -171,12 +180,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
-int groupnorm_run(const void* x, void* y, const float* gamma, const float* beta, int n_img, int hw, int c, int groups,
-                  float eps, int silu, int dtype, void* stats_ws, hipStream_t s) {
+int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, const float* beta, int n_img, int hw, int c0,
+                  int c1, int groups, float eps, int silu, int dtype, void* stats_ws, hipStream_t s) {
     MVLDM_REQUIRE(x && y && gamma && beta && stats_ws, "groupnorm: null pointer");
+    MVLDM_REQUIRE((c1 == 0) == (x1 == nullptr), "groupnorm: x1/c1 mismatch");
+    const int c = c0 + c1;
     MVLDM_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0, "groupnorm: c=%d groups=%d", c, groups);
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
-    MVLDM_REQUIRE(c % epc == 0, "groupnorm: c=%d must be a multiple of %d", c, epc);
+    MVLDM_REQUIRE(c0 % epc == 0 && c1 % epc == 0, "groupnorm: channels (%d,%d) must be multiples of %d", c0, c1, epc);
     if (n_img == 0 || hw == 0) return MVLDM_OK;
     // slabs: enough workgroups to cover the chip, at least 8 rows each
     int nchunk = std::min(MVLDM_GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, (1024 + n_img - 1) / n_img)));
@@ -186,11 +197,12 @@ int groupnorm_run(const void* x, void* y, const float* gamma, const float* beta,
     return dispatch_dtype(dtype, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(n_img * nchunk), dim3(256), 0, s, reinterpret_cast<const T*>(x),
-                           reinterpret_cast<double*>(stats_ws), hw, c, groups, rows_per_chunk, nchunk);
+                           reinterpret_cast<const T*>(x1), c0, reinterpret_cast<double*>(stats_ws), hw, c, groups,
+                           rows_per_chunk, nchunk);
         int rc = check_launch();
         if (rc) return rc;
         hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(n_img * nchunk), dim3(256), smem, s, reinterpret_cast<const T*>(x),
-                           reinterpret_cast<T*>(y), gamma, beta, reinterpret_cast<const double*>(stats_ws), hw, c, groups,
+                           reinterpret_cast<const T*>(x1), c0, reinterpret_cast<T*>(y), gamma, beta, reinterpret_cast<const double*>(stats_ws), hw, c, groups,
                            rows_per_chunk, nchunk, eps, silu);
         return check_launch();
     });
@@ -220,10 +232,11 @@ int layernorm_run(const void* x, void* y, const float* gamma, const float* beta,
 
 }  // namespace mvldm
 
-extern "C" int mvldm_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, int n_img, int hw,
-                                   int c, int groups, float eps, int silu, int dtype, void* stats_ws,
-                                   mvldm_stream_t stream) {
-    return mvldm::groupnorm_run(x, y, gamma, beta, n_img, hw, c, groups, eps, silu, dtype, stats_ws, (hipStream_t)stream);
+extern "C" int mvldm_groupnorm_fwd(const void* x0, const void* x1, void* y, const float* gamma, const float* beta,
+                                   int n_img, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
+                                   void* stats_ws, mvldm_stream_t stream) {
+    return mvldm::groupnorm_run(x0, x1, y, gamma, beta, n_img, hw, c0, c1, groups, eps, silu, dtype, stats_ws,
+                                (hipStream_t)stream);
 }
 
 extern "C" int mvldm_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, int rows, int c,

@@ -6,8 +6,8 @@
 
 namespace mvldm {
 int igemm_run(const mvldm_igemm_desc& d, hipStream_t s);
-int groupnorm_run(const void* x, void* y, const float* gamma, const float* beta, int n_img, int hw, int c, int groups,
-                  float eps, int silu, int dtype, void* stats_ws, hipStream_t s);
+int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, const float* beta, int n_img, int hw, int c0,
+                  int c1, int groups, float eps, int silu, int dtype, void* stats_ws, hipStream_t s);
 int layernorm_run(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps, int dtype,
                   hipStream_t s);
 int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,
@@ -29,7 +29,8 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         case MVLDM_OP_IGEMM: return igemm_run(op.u.igemm, s);
         case MVLDM_OP_GROUPNORM: {
             const auto& g = op.u.groupnorm;
-            return groupnorm_run(g.x, g.y, g.gamma, g.beta, g.n_img, g.hw, g.c, g.groups, g.eps, g.silu, g.dtype, g.stats_ws, s);
+            return groupnorm_run(g.x, g.x1, g.y, g.gamma, g.beta, g.n_img, g.hw, g.c0, g.c1, g.groups, g.eps, g.silu, g.dtype,
+                                 g.stats_ws, s);
         }
         case MVLDM_OP_LAYERNORM: {
             const auto& l = op.u.layernorm;
@@ -84,6 +85,11 @@ struct mvldm_plan {
 };
 
 using namespace mvldm;
+
+extern "C" int mvldm_op_run(const mvldm_op* op, mvldm_stream_t stream) {
+    MVLDM_REQUIRE(op, "op_run: null op");
+    return run_op(*op, (hipStream_t)stream);
+}
 
 extern "C" int mvldm_plan_create(const mvldm_op* ops, int n_ops, mvldm_plan** out) {
     MVLDM_REQUIRE(ops && out && n_ops >= 0, "plan_create: bad arguments");

@@ -1,0 +1,422 @@
+"""The multi-view denoiser behind the reference's plug-in registries.
+
+Mirrors (same names, argument meaning and error behaviour):
+  * `DENOISER` / `get_denoiser`          src/model/denoiser/__init__.py:7-18
+  * `Denoiser.forward(latents[b,v,c,h,w], timestep[b | b,v], cond_state=None)`   denoiser.py:12-29
+  * `MultiViewUNetCfg`, `UNet2DModelCfg`, `MultiViewUNet`                         mvunet.py:22-208
+  * `get_attn_blocks(cfg, unet_blocks)`                                            denoiser/attention.py:8-27
+  * `SpatialTransformer3DCfg`, `SpatialTransformer3D`                              mvdream/attention.py:24-32,371-439
+State-dict keys are the reference's (`unet.*`, `cross_attn_blocks_{encoder,mid,decoder}.*`).
+
+`MultiViewUNet.forward` runs the WHOLE walk of mvunet.py:90-208 as one C-side plan (see `emit`):
+  - all 22 `time_emb_proj(silu(emb))` of the pass are one GEMM issued up front;
+  - the skip concat (mvunet.py:176) is never materialised: GroupNorm / the 1x1 shortcut read two sources;
+  - SD cross-attention to the all-zero context (mvunet.py:124-128) is exactly `to_out.bias`
+    (k = v = 0): folded into the preceding projection's bias, no kernel at all;
+  - views that attend to each other are described by `groups` (views per scene), so the conditional
+    and unconditional CFG passes of DiffusionWrapper.step can share ONE forward ([v_c+v_t, v_t]).
+`forward_walk` is the literal module-by-module walk (each kernel launched eagerly through the
+diffusers-style surface), kept as the readable specification and for `cond_state` != None.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .modules import (Attention, Builder, Conv2d, FeedForward, GroupNorm, LayerNorm, UNet2DConditionModel, _PackMixin,
+                      _segments, eager_builder)
+from .runtime import from_nhwc, get_compute_dtype, require_gpu, to_nhwc
+
+
+# ------------------------------------------------------------------------------------------ configs
+@dataclass
+class SpatialTransformer3DCfg:
+    name: str = "spatial_transformer_3d"
+    num_heads: int = 8
+    num_layers: int = 1
+    d_dot: Optional[int] = None
+    d_mlp: Optional[int] = None
+    d_mlp_multiplier: Optional[int] = None   # ignored by the reference as well
+    downscale: int = 1
+    pos_enc: bool = False
+
+
+MultiViewAttentionCfg = SpatialTransformer3DCfg
+
+
+@dataclass
+class UNet2DModelCfg:
+    name: str = "unet"
+    down_block_types: Sequence[str] = ("DownBlock2D",) * 4
+    mid_block_type: str = "UNetMidBlock2D"
+    up_block_types: Sequence[str] = ("UpBlock2D",) * 4
+    only_cross_attention: bool = False
+    block_out_channels: Sequence[int] = (320, 640, 1280, 1280)
+
+
+@dataclass
+class MultiViewUNetCfg:
+    name: str = "mv_unet"
+    autoencoder: UNet2DModelCfg = field(default_factory=UNet2DModelCfg)
+    multi_view_attention: MultiViewAttentionCfg = field(default_factory=SpatialTransformer3DCfg)
+    use_ray_encoding: bool = True
+    encoder_conditioning: bool = True
+    mid_conditioning: bool = True
+    decoder_conditioning: bool = True
+    pretrained_from: Optional[str] = None
+    # not in the reference: lets tests / benches build the SD-2.1 *topology* at other widths, and
+    # hands a diffusers-layout state dict to `from_pretrained` (no hub access offline)
+    pretrained_overrides: Optional[dict] = None
+    pretrained_state_dict: Optional[dict] = None
+
+
+# ------------------------------------------------------------------------------------------ MV attention
+class CrossAttention(Attention):
+    """mvdream/attention.py:156-205 (`to_out` is Sequential(Linear, Dropout): same keys as ModuleList)"""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__(query_dim, context_dim, heads, dim_head)
+
+
+class BasicTransformerBlock3D(nn.Module):
+    """mvdream/attention.py:257-296,357-368: attn1 over ALL views' tokens of a scene, attn2 per view."""
+
+    def __init__(self, dim, n_heads, d_head):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, n_heads, d_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, None, n_heads, d_head)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.norm3 = LayerNorm(dim)
+
+    def emit(self, b: Builder, hs, groups: Sequence[int], tokens: int):
+        scene_lens = [g * tokens for g in groups]
+        view_lens = [tokens] * sum(groups)
+        n1 = self.norm1.emit(b, hs, name="norm1")
+        h1 = self.attn1.emit_self(b, n1, hs, _segments(b, scene_lens), scene_lens, name="attn1_3d")
+        b.free(n1)
+        n2 = self.norm2.emit(b, h1, name="norm2")
+        h2 = self.attn2.emit_self(b, n2, h1, _segments(b, view_lens), view_lens, name="attn2_view")
+        b.free(n2)
+        b.free(h1)
+        n3 = self.norm3.emit(b, h2, name="norm3")
+        out = self.ff.emit(b, n3, h2, name="ff")
+        b.free(n3)
+        b.free(h2)
+        return out
+
+
+class SpatialTransformer3D(nn.Module):
+    """mvdream/attention.py:371-439 (`use_linear=False`).  `proj_out` is zero-initialised like the
+    reference's `zero_module` (:407-411)."""
+
+    def __init__(self, cfg: SpatialTransformer3DCfg, d_in: int):
+        super().__init__()
+        n_heads = cfg.num_heads
+        d_head = cfg.d_dot or d_in // n_heads
+        self.in_channels = d_in
+        self.norm = GroupNorm(32, d_in, eps=1e-6)
+        self.proj_in = Conv2d(d_in, d_in, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock3D(d_in, n_heads, d_head) for _ in range(cfg.num_layers)])
+        self.proj_out = Conv2d(d_in, d_in, 1)
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
+
+    def emit(self, b: Builder, x, groups: Sequence[int]):
+        """x: NHWC [sum(groups), h, w, C]; `groups` = number of views of each scene."""
+        n, h, w, c = x.shape
+        assert n == sum(groups)
+        g = self.norm.emit(b, x, name="norm")
+        hs = b.linear(g.view(n * h * w, c), self.proj_in.packed(b.dtype, c), self.proj_in._f32("bias"), name="proj_in")
+        b.free(g)
+        for i, blk in enumerate(self.transformer_blocks):
+            with b.scope(f"transformer_blocks.{i}"):
+                nxt = blk.emit(b, hs, groups, h * w)
+            b.free(hs)
+            hs = nxt
+        out = b.linear(hs, self.proj_out.packed(b.dtype, c), self.proj_out._f32("bias"), residual=x.view(n * h * w, c), name="proj_out")
+        b.free(hs)
+        return out.view(n, h, w, c)
+
+    def forward(self, x, context=None):
+        bsz, v, c, h, w = x.shape
+        b = eager_builder(x)
+        y = self.emit(b, to_nhwc(x.reshape(bsz * v, c, h, w), b.dtype), [v] * bsz)
+        return from_nhwc(y).reshape(bsz, v, c, h, w)
+
+
+def get_attn_blocks(cfg: MultiViewAttentionCfg, unet_blocks) -> nn.ModuleList:
+    """src/model/denoiser/attention.py:8-27"""
+    if cfg.name == "spatial_transformer_3d":
+        return nn.ModuleList([SpatialTransformer3D(cfg=cfg, d_in=block.resnets[-1].out_channels) for block in unet_blocks])
+    raise NotImplementedError(f"multi_view_attention '{cfg.name}' (only spatial_transformer_3d is on the released path)")
+
+
+# ------------------------------------------------------------------------------------------ denoiser
+class Denoiser(nn.Module):
+    """src/model/denoiser/denoiser.py:12-29"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+
+class MultiViewUNet(Denoiser, _PackMixin):
+    def __init__(self, cfg: MultiViewUNetCfg, in_channels: int, out_channels: int):
+        super().__init__(cfg)
+        self.use_ray_encoding = cfg.use_ray_encoding
+        self.pretrained_from = cfg.pretrained_from
+        a = cfg.autoencoder
+        if self.pretrained_from is None:
+            self.unet = UNet2DConditionModel(
+                in_channels=in_channels, out_channels=out_channels, down_block_types=a.down_block_types,
+                mid_block_type=a.mid_block_type, up_block_types=a.up_block_types,
+                only_cross_attention=a.only_cross_attention, block_out_channels=a.block_out_channels,
+                cross_attention_dim=list(a.block_out_channels))
+        else:
+            self.unet = UNet2DConditionModel.from_pretrained(self.pretrained_from, subfolder="unet",
+                                                             config_overrides=getattr(cfg, "pretrained_overrides", None),
+                                                             state_dict=getattr(cfg, "pretrained_state_dict", None))
+            c0 = self.unet.config.block_out_channels[0]
+            self.unet.conv_in = Conv2d(in_channels, c0, kernel_size=3, padding=1)
+            self.unet.conv_out = Conv2d(c0, out_channels, kernel_size=3, padding=1)
+        if cfg.encoder_conditioning:
+            self.cross_attn_blocks_encoder = get_attn_blocks(cfg.multi_view_attention, self.unet.down_blocks)
+        if cfg.mid_conditioning:
+            self.cross_attn_blocks_mid = get_attn_blocks(cfg.multi_view_attention, [self.unet.mid_block])
+        if cfg.decoder_conditioning:
+            self.cross_attn_blocks_decoder = get_attn_blocks(cfg.multi_view_attention, self.unet.up_blocks)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._plans = {}
+
+    # ---- fused whole-forward emission -------------------------------------------------------------
+    def _resnets_in_order(self) -> List:
+        u = self.unet
+        rs = [r for blk in u.down_blocks for r in blk.resnets] + list(u.mid_block.resnets)
+        return rs + [r for blk in u.up_blocks for r in blk.resnets]
+
+    def _temb_proj_all(self, b: Builder, emb_act):
+        """all `time_emb_proj` of the pass in ONE GEMM -> {resnet: fp32 [n_img, C_out] column slice}"""
+        rs = self._resnets_in_order()
+        ws = [r.time_emb_proj.weight for r in rs]
+        bs = [r.time_emb_proj.bias for r in rs]
+        pw = self._cache(("tproj", b.dtype), ws, lambda: ops.pack_weight(torch.cat([w.detach() for w in ws], 0), b.dtype))
+        bias = self._cache(("tprojb",), bs, lambda: torch.cat([x.detach().float() for x in bs], 0).contiguous())
+        allp = b.linear(emb_act, pw, bias, out_dtype=torch.float32, name="time_emb_proj[all]")
+        out, off = {}, 0
+        for r in rs:
+            out[id(r)] = allp[:, off:off + r.out_channels]
+            off += r.out_channels
+        return out
+
+    def _zero_ctx_ok(self, cond_state) -> bool:
+        # cond_state is None on every call the reference makes (diffusion_wrapper.py:401,435,441)
+        return cond_state is None
+
+    def emit(self, b: Builder, x_in, timesteps, groups: Sequence[int], out: Optional[torch.Tensor] = None):
+        """x_in: NHWC [n_img, h, w, c_pad] (11 real channels, zero padded); timesteps: int64 [n_img];
+        groups: views per scene for the 3-D attention.  Returns eps, fp32 NHWC [n_img, h, w, out_channels]."""
+        u = self.unet
+        n_img = x_in.shape[0]
+        assert n_img == sum(groups)
+        with b.scope("time"):
+            t_emb = u.time_proj.emit(b, timesteps, dtype=b.dtype)
+            emb_act = u.time_embedding.emit(b, t_emb, silu_out=True)   # every consumer applies SiLU first
+            b.free(t_emb)
+            tproj = self._temb_proj_all(b, emb_act)
+            b.free(emb_act)
+
+        def resnet(r, name, h, skip=None):
+            with b.scope(name):
+                return r.emit(b, h, None, x2=skip, temb_proj=tproj[id(r)])
+
+        def sd_attn(attn, name, h):
+            with b.scope(name):
+                return attn.emit(b, h, None, zero_ctx=True)
+
+        def mv(blocks, idx, name, h):
+            with b.scope(name):
+                return blocks[idx].emit(b, h, groups)
+
+        with b.scope("conv_in"):
+            h = u.conv_in.emit(b, x_in, name="conv")
+        skips = [h]
+        live_mv = None  # an MV-block output that is not a skip (freed once consumed)
+        for lvl, blk in enumerate(u.down_blocks):
+            has_attn = getattr(blk, "has_cross_attention", False)
+            for i, r in enumerate(blk.resnets):
+                nh = resnet(r, f"down{lvl}.resnets.{i}", h)
+                if live_mv is not None:
+                    b.free(live_mv)
+                    live_mv = None
+                h = nh
+                if has_attn:
+                    h2 = sd_attn(blk.attentions[i], f"down{lvl}.attentions.{i}", h)
+                    b.free(h)
+                    h = h2
+                skips.append(h)
+            if h.shape[1] <= 32 and h.shape[2] <= 32 and self.cfg.encoder_conditioning:
+                h = mv(self.cross_attn_blocks_encoder, lvl, f"mv_encoder.{lvl}", h)
+                live_mv = h
+            if blk.downsamplers is not None:
+                for d in blk.downsamplers:
+                    with b.scope(f"down{lvl}.downsample"):
+                        nh = d.emit(b, h)
+                    if live_mv is not None:
+                        b.free(live_mv)
+                        live_mv = None
+                    h = nh
+                skips.append(h)
+
+        mid = u.mid_block
+        nh = resnet(mid.resnets[0], "mid.resnets.0", h)
+        if live_mv is not None:
+            b.free(live_mv)
+            live_mv = None
+        h = nh
+        for i, (attn, r) in enumerate(zip(mid.attentions, mid.resnets[1:])):
+            h2 = sd_attn(attn, f"mid.attentions.{i}", h)
+            b.free(h)
+            h3 = resnet(r, f"mid.resnets.{i + 1}", h2)
+            b.free(h2)
+            h = h3
+        if self.cfg.mid_conditioning:
+            h2 = mv(self.cross_attn_blocks_mid, 0, "mv_mid", h)
+            b.free(h)
+            h = h2
+
+        for lvl, blk in enumerate(u.up_blocks):
+            has_attn = getattr(blk, "has_cross_attention", False) and self.pretrained_from is None
+            for i, r in enumerate(blk.resnets):
+                skip = skips.pop()
+                nh = resnet(r, f"up{lvl}.resnets.{i}", h, skip)
+                b.free(h)
+                b.free(skip)
+                h = nh
+                if has_attn:
+                    h2 = sd_attn(blk.attentions[i], f"up{lvl}.attentions.{i}", h)
+                    b.free(h)
+                    h = h2
+            if h.shape[1] <= 32 and h.shape[2] <= 32 and self.cfg.decoder_conditioning:
+                h2 = mv(self.cross_attn_blocks_decoder, lvl, f"mv_decoder.{lvl}", h)
+                b.free(h)
+                h = h2
+            if blk.upsamplers is not None:
+                for up in blk.upsamplers:
+                    with b.scope(f"up{lvl}.upsample"):
+                        h2 = up.emit(b, h)
+                    b.free(h)
+                    h = h2
+        with b.scope("out"):
+            g = u.conv_norm_out.emit(b, h, silu=True, name="conv_norm_out+silu")
+            b.free(h)
+            eps = u.conv_out.emit(b, g, out_dtype=torch.float32, out=out, name="conv_out")
+            b.free(g)
+        return eps
+
+    # ---- drop-in forward ---------------------------------------------------------------------------
+    def compile(self, b_scenes: int, views: int, h: int, w: int, dtype=None, graph: bool = True):
+        """build (and cache) the plan for latents [b, v, in_channels, h, w]"""
+        dtype = dtype or get_compute_dtype()
+        dev = next(self.parameters()).device
+        key = (b_scenes, views, h, w, dtype, str(dev), graph)
+        st = self._plans.get(key)
+        if st is not None:
+            return st
+        n = b_scenes * views
+        bld = Builder(dev, dtype, record=True)
+        c_pad = (self.in_channels + ops.epc(dtype) - 1) // ops.epc(dtype) * ops.epc(dtype)
+        lat = torch.zeros(n, self.in_channels, h, w, dtype=torch.float32, device=dev)
+        ts = torch.zeros(n, dtype=torch.int64, device=dev)
+        x_in = torch.zeros(n, h, w, c_pad, dtype=dtype, device=dev)
+        out = torch.zeros(n, self.out_channels, h, w, dtype=torch.float32, device=dev)
+        bld.nchw_to_nhwc(lat, x_in)
+        eps = self.emit(bld, x_in, ts, [views] * b_scenes)
+        bld.nhwc_to_nchw(eps, out)
+        plan = bld.finalize()
+        if graph:
+            plan.capture()
+        st = dict(plan=plan, lat=lat, ts=ts, out=out, graph=graph)
+        self._plans[key] = st
+        return st
+
+    def forward(self, latents, timestep, cond_state=None):
+        """latents [b, v, c, h, w]; timestep int64 [b] or [b, v] -> [b, v, out_channels, h, w] (fp32)."""
+        require_gpu(latents)
+        if not self._zero_ctx_ok(cond_state):
+            return self.forward_walk(latents, timestep, cond_state)
+        bsz, v, c, h, w = latents.shape
+        st = self.compile(bsz, v, h, w)
+        t = timestep.reshape(bsz, -1)
+        t = (t.expand(bsz, v) if t.shape[1] == 1 else t).reshape(bsz * v)
+        st["lat"].copy_(latents.reshape(bsz * v, c, h, w))
+        st["ts"].copy_(t)
+        st["plan"].replay() if st["graph"] else st["plan"].run()
+        return st["out"].view(bsz, v, self.out_channels, h, w).clone()
+
+    def forward_walk(self, latents, timestep, cond_state=None):
+        """The walk of mvunet.py:90-208, one diffusers-style module call at a time (eager kernels)."""
+        bsz, v = latents.shape[:2]
+        u = self.unet
+        t = timestep.reshape(bsz, -1)
+        t = (t.expand(bsz, v) if t.shape[1] == 1 else t).reshape(bsz * v).to(torch.int64)
+        emb = u.time_embedding(u.time_proj(t))
+        hs = u.conv_in(latents.reshape(bsz * v, *latents.shape[2:]))
+        skips = [hs]
+
+        def ctx_for(x):
+            if self.pretrained_from is not None:            # mvunet.py:127-128
+                return torch.zeros(bsz * v, 1, 1024, device=x.device)
+            if cond_state is None:                           # mvunet.py:124-125
+                return torch.zeros(x.shape[0], x.shape[2] * x.shape[3], x.shape[1], device=x.device)
+            return cond_state
+
+        def mv(block, x):
+            n, c, hh, ww = x.shape
+            return block(x.reshape(bsz, v, c, hh, ww)).reshape(n, c, hh, ww)
+
+        for lvl, blk in enumerate(u.down_blocks):
+            for i, r in enumerate(blk.resnets):
+                hs = r(hs, emb)
+                if getattr(blk, "has_cross_attention", False):
+                    hs = blk.attentions[i](hs, encoder_hidden_states=ctx_for(hs)).sample
+                skips.append(hs)
+            if hs.shape[-2] <= 32 and hs.shape[-1] <= 32 and self.cfg.encoder_conditioning:
+                hs = mv(self.cross_attn_blocks_encoder[lvl], hs)
+            if blk.downsamplers is not None:
+                for d in blk.downsamplers:
+                    hs = d(hs)
+                skips.append(hs)
+        hs = u.mid_block.resnets[0](hs, emb)
+        for attn, r in zip(u.mid_block.attentions, u.mid_block.resnets[1:]):
+            hs = attn(hs, encoder_hidden_states=ctx_for(hs)).sample
+            hs = r(hs, emb)
+        if self.cfg.mid_conditioning:
+            hs = mv(self.cross_attn_blocks_mid[0], hs)
+        for lvl, blk in enumerate(u.up_blocks):
+            for i, r in enumerate(blk.resnets):
+                hs = r(torch.cat((hs, skips.pop()), dim=1), emb)
+                if getattr(blk, "has_cross_attention", False) and self.pretrained_from is None:
+                    hs = blk.attentions[i](hs, encoder_hidden_states=ctx_for(hs)).sample
+            if hs.shape[-2] <= 32 and hs.shape[-1] <= 32 and self.cfg.decoder_conditioning:
+                hs = mv(self.cross_attn_blocks_decoder[lvl], hs)
+            if blk.upsamplers is not None:
+                for up in blk.upsamplers:
+                    hs = up(hs)
+        hs = u.conv_out(u.conv_act(u.conv_norm_out(hs)))
+        return hs.float().reshape(bsz, v, *hs.shape[1:])
+
+
+DENOISER = {"mv_unet": MultiViewUNet}
+DenoiserCfg = MultiViewUNetCfg
+
+
+def get_denoiser(denoiser_cfg: DenoiserCfg, in_channels: int, out_channels: int) -> Denoiser:
+    """src/model/denoiser/__init__.py:13-18"""
+    return DENOISER[denoiser_cfg.name](denoiser_cfg, in_channels, out_channels)

@@ -101,6 +101,7 @@ def igemm_desc(src0, src1, pw: PackedWeight, dst, *, n_img, h_in, w_in, h_out, w
     d.row_bias_ld = 0 if row_bias is None else row_bias.stride(0)
     d.epilogue, d.act_dtype, d.dst_dtype = epilogue, dt(src0), dt(dst)
     d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
+    d.dst_ld = 0
     if ws is not None:
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     else:
@@ -143,15 +144,16 @@ def linear(x: torch.Tensor, pw: PackedWeight, bias=None, *, residual=None, epilo
 
 
 # ------------------------------------------------------------------------------------------ norms
-def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool) -> torch.Tensor:
-    """x NHWC `[n, h, w, c]` (or `[n, hw, c]`)."""
-    assert x.is_cuda and x.is_contiguous()
-    n, c = x.shape[0], x.shape[-1]
-    hw = x.numel() // (n * c)
-    y = torch.empty_like(x)
+def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool, x2=None) -> torch.Tensor:
+    """x NHWC `[n, h, w, c]` (or `[n, hw, c]`); x2: optional second source concatenated along c."""
+    assert x.is_cuda and x.is_contiguous() and (x2 is None or x2.is_contiguous())
+    n, c0 = x.shape[0], x.shape[-1]
+    c1 = 0 if x2 is None else x2.shape[-1]
+    hw = x.numel() // (n * c0)
+    y = torch.empty(*x.shape[:-1], c0 + c1, dtype=x.dtype, device=x.device)
     ws = workspace(n * L.GN_MAX_CHUNKS * groups * 2 * 8, x.device, "gn")
-    L.check(L.load().mvldm_groupnorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, hw, c, groups,
-                                         eps, int(silu), dt(x), ws.data_ptr(), stream()))
+    L.check(L.load().mvldm_groupnorm_fwd(x.data_ptr(), ptr(x2), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, hw, c0, c1,
+                                         groups, eps, int(silu), dt(x), ws.data_ptr(), stream()))
     return y
 
 

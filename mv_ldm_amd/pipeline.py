@@ -1,0 +1,228 @@
+"""Sampling harness: the counterpart of `DiffusionWrapper`'s inference methods
+(src/model/diffusion_wrapper.py) on the HIP path.
+
+  geometry      `sample_image_grid`, `get_world_rays` (src/geometry/projection.py:117-138,91-114),
+                `absolute_to_relative_camera` (src/misc/camera_utils.py:7-25)  -- tiny host-side fp32
+                torch algebra, once per `sample()` ("host-side is fine")
+  MVLDMPipeline `first_stage_encode` (:278-287), `last_stage_decode` (:289-298), `ray_encode`
+                (:301-322), `step` (:413-453), `sample` (:455-490)
+
+`step()` is the literal reference sequence (two denoiser forwards, CFG compose, scheduler step) on
+the drop-in module objects.  `sample()` is the production path: ONE recorded plan per shape holds the
+conditional and the unconditional pass as a single UNet forward over `groups = [v_c+v_t]*b + [v_t]*b`
+(weights are read once for both), the fused CFG+DDIM kernel and the step bookkeeping; it is captured
+into a hipGraph and replayed N times with no Python or host synchronisation in the loop.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+from .mvunet import MultiViewUNet
+from .plan import Builder
+from .runtime import get_compute_dtype
+from .scheduler import DDIMScheduler
+from .vae import AutoencoderKL
+
+VAE_SCALE = 0.18215  # diffusion_wrapper.py:283,293
+
+
+# ------------------------------------------------------------------------------------------ geometry
+def sample_image_grid(shape, device="cpu", dtype=torch.float32):
+    """pixel centres in (0,1), last dim (x, y); integer (row, col) indices.  projection.py:117-138"""
+    h, w = shape
+    ys = ((torch.arange(h, device=device) + 0.5) / h).to(dtype)
+    xs = ((torch.arange(w, device=device) + 0.5) / w).to(dtype)
+    gx, gy = torch.meshgrid(xs, ys, indexing="xy")
+    ii, jj = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+    return torch.stack([gx, gy], dim=-1), torch.stack([ii, jj], dim=-1)
+
+
+def get_world_rays(coordinates, extrinsics, intrinsics):
+    """coordinates [..., 2]; extrinsics [..., 4, 4] camera-to-world; intrinsics [..., 3, 3] normalised.
+    Returns (origins, directions) [..., 3].  projection.py:74-114"""
+    pix = torch.cat([coordinates, torch.ones_like(coordinates[..., :1])], dim=-1)
+    d = torch.einsum("...ij,...j->...i", intrinsics.inverse(), pix)
+    d = d * torch.ones_like(coordinates[..., 0])[..., None]
+    d = d / d.norm(dim=-1, keepdim=True)
+    d = torch.cat([d, torch.zeros_like(d[..., :1])], dim=-1)
+    d = torch.einsum("...ij,...j->...i", extrinsics, d)[..., :3]
+    return extrinsics[..., :3, 3].broadcast_to(d.shape), d
+
+
+def absolute_to_relative_camera(tform, index: int):
+    """inv(T[index]) @ T.  camera_utils.py:7-25"""
+    ref = tform[:, index:index + 1].expand(-1, tform.shape[1], -1, -1)
+    return torch.linalg.inv(ref) @ tform
+
+
+def ray_encode(ctx_extr, ctx_intr, tgt_extr, tgt_intr, hl: int, wl: int):
+    """[b, v_c+v_t, 6, hl, wl]: ray origins then directions (raw; `use_ray_encoding`,
+    `srt_ray_encoding`, `use_plucker` all off in the released config).  diffusion_wrapper.py:169-190,301-322"""
+    def rays(extr, intr):
+        xy, _ = sample_image_grid((hl, wl), device=extr.device, dtype=extr.dtype)
+        return get_world_rays(xy.reshape(hl * wl, 2), extr[:, :, None], intr[:, :, None])
+    oc, dc = rays(ctx_extr, ctx_intr)
+    ot, dt_ = rays(tgt_extr, tgt_intr)
+    enc = torch.cat([torch.cat([oc, ot], dim=1), torch.cat([dc, dt_], dim=1)], dim=-1)
+    b, v = enc.shape[:2]
+    return enc.reshape(b, v, hl, wl, 6).permute(0, 1, 4, 2, 3).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ pipeline
+@dataclass
+class SamplerCfg:
+    use_cfg: bool = True       # config/main.yaml:30
+    cfg_scale: float = 3.0     # config/main.yaml:31
+    num_inference_steps: int = 50
+
+
+class MVLDMPipeline:
+    def __init__(self, denoiser: MultiViewUNet, autoencoder: AutoencoderKL, scheduler: DDIMScheduler,
+                 cfg: Optional[SamplerCfg] = None):
+        self.denoiser, self.autoencoder, self.scheduler = denoiser, autoencoder, scheduler
+        self.cfg = cfg or SamplerCfg()
+        self._plans = {}
+
+    @property
+    def device(self):
+        return next(self.denoiser.parameters()).device
+
+    def set_timesteps(self, num: Optional[int] = None):
+        self.scheduler.set_timesteps(self.cfg.num_inference_steps if num is None else num)
+
+    # ---- VAE wrappers (diffusion_wrapper.py:278-298) -----------------------------------------------
+    def first_stage_encode(self, images, noise=None, generator=None):
+        b, v = images.shape[:2]
+        x = (images.reshape(b * v, *images.shape[2:]).to(self.device, torch.float32) * 2.0 - 1.0).contiguous()
+        z = self.autoencoder.encode(x).latent_dist.sample(generator=generator, noise=noise) * VAE_SCALE
+        return z.reshape(b, v, *z.shape[1:])
+
+    def last_stage_decode(self, latents):
+        b, v = latents.shape[:2]
+        z = ((1 / VAE_SCALE) * latents.reshape(b * v, *latents.shape[2:]).to(self.device, torch.float32)).contiguous()
+        img = self.autoencoder.decode(z).sample
+        img = img.reshape(b, v, *img.shape[1:])
+        return (img / 2 + 0.5).clamp(0, 1)
+
+    # ---- the reference's step, literally (diffusion_wrapper.py:413-453) ----------------------------
+    def step(self, model, x_t, ts, context_inputs, ray_encodings, target_mask):
+        b, v_c = context_inputs.shape[:2]
+        v_t = x_t.shape[1]
+        dev = x_t.device
+        x_in = self.scheduler.scale_model_input(x_t, ts)
+        t_tgt = torch.as_tensor(ts).to(torch.long).reshape(1).expand(b).to(dev)
+        timesteps = torch.cat([torch.zeros(b, v_c, dtype=torch.long, device=dev), t_tgt[:, None].expand(b, v_t)], dim=1)
+        target_inputs = torch.cat([x_in, target_mask], dim=2)
+        inputs = torch.cat([torch.cat([context_inputs, target_inputs], dim=1), ray_encodings], dim=2)
+        pred_c = model.forward(inputs, timesteps)
+        if self.cfg.use_cfg:
+            inputs_u = torch.cat([target_inputs, ray_encodings[:, v_c:]], dim=2)
+            pred_u = model.forward(inputs_u, t_tgt[:, None].expand(b, v_t))
+            # CFG compose + DDIM update: one fused HIP kernel
+            return self._cfg_ddim(pred_c[:, v_c:].contiguous(), pred_u, x_t, ts)
+        return self.scheduler.step(pred_c[:, v_c:].contiguous(), ts, x_t).prev_sample
+
+    def _cfg_ddim(self, pred_c, pred_u, x_t, ts):
+        dev = x_t.device
+        coef = self.scheduler.step_coefficients(int(ts)).reshape(1, 4).to(dev)
+        zero = torch.zeros(1, dtype=torch.int32, device=dev)
+        eps = torch.stack([pred_c.float().reshape(-1), pred_u.float().reshape(-1)]).view(2, 1, -1, 1).contiguous()
+        out = ops.ddim_cfg_step(eps, x_t.float().contiguous().view(1, 1, -1, 1), zero, torch.ones(1, dtype=torch.int32, device=dev),
+                                self.cfg.cfg_scale, coef, zero, None)
+        return out.view(x_t.shape)
+
+    # ---- production sampler ------------------------------------------------------------------------
+    def _compile(self, b: int, v_c: int, v_t: int, hl: int, wl: int, dtype, n_steps: int):
+        key = (b, v_c, v_t, hl, wl, dtype, n_steps, self.cfg.use_cfg, self.cfg.cfg_scale, str(self.device))
+        st = self._plans.get(key)
+        if st is not None:
+            return st
+        dev, den = self.device, self.denoiser
+        lc = den.out_channels
+        use_cfg = self.cfg.use_cfg
+        v = v_c + v_t
+        n_cond, n_unc = b * v, (b * v_t if use_cfg else 0)
+        n_img = n_cond + n_unc
+        e = ops.epc(dtype)
+        c_pad = (den.in_channels + e - 1) // e * e
+        unet_in = torch.zeros(n_img, hl, wl, c_pad, dtype=dtype, device=dev)
+        x_state = torch.zeros(b * v_t, hl, wl, lc, dtype=torch.float32, device=dev)
+        eps = torch.zeros(n_img, hl, wl, lc, dtype=torch.float32, device=dev)
+        timesteps = torch.zeros(n_img, dtype=torch.int64, device=dev)
+        cond_img = torch.tensor([s * v + v_c + j for s in range(b) for j in range(v_t)], dtype=torch.int32, device=dev)
+        unc_img = (torch.tensor([n_cond + s * v_t + j for s in range(b) for j in range(v_t)], dtype=torch.int32, device=dev)
+                   if use_cfg else None)
+        tgt_rows = cond_img if not use_cfg else torch.cat([cond_img, unc_img])
+        sch = self.scheduler
+        t_table = sch.timesteps.to(dev, torch.int64).contiguous()
+        coef = sch.coefficient_table().to(dev)
+        step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        groups = [v] * b + ([v_t] * b if use_cfg else [])
+        bld = Builder(dev, dtype, record=True)
+        with bld.scope("unet"):
+            den.emit(bld, unet_in, timesteps, groups, out=eps)
+        bld.ddim_step(eps, x_state, x_state, cond_img, unc_img, self.cfg.cfg_scale, coef, step_ptr, unet_in)
+        bld.ddim_advance(step_ptr, t_table, timesteps, tgt_rows)
+        plan = bld.finalize()
+        plan.capture()
+        st = dict(plan=plan, unet_in=unet_in, x_state=x_state, eps=eps, timesteps=timesteps, cond_img=cond_img,
+                  unc_img=unc_img, tgt_rows=tgt_rows, t_table=t_table, step_ptr=step_ptr, n_cond=n_cond)
+        self._plans[key] = st
+        return st
+
+    def load_inputs(self, st, ctx_latents, x_T, rays, v_c: int):
+        """write the per-sample constants into the UNet input buffer: [latent 0..3 | mask 4 | rays 5..10]
+        (diffusion_wrapper.py:429-432,476-481); context views are clean (mask 0, timestep 0)."""
+        dev, ui = self.device, st["unet_in"]
+        b, v_t = x_T.shape[:2]
+        v = v_c + v_t
+        lc = x_T.shape[2]
+        dtype = ui.dtype
+        nhwc = lambda t: t.to(dev, torch.float32).permute(0, 1, 3, 4, 2)        # [b, v, h, w, c]
+        ui.zero_()
+        cond = ui[:st["n_cond"]].view(b, v, *ui.shape[1:])
+        cond[:, :v_c, ..., :lc] = nhwc(ctx_latents).to(dtype)
+        cond[:, v_c:, ..., :lc] = nhwc(x_T).to(dtype)
+        cond[:, v_c:, ..., lc] = 1.0
+        cond[..., lc + 1:lc + 7] = nhwc(rays).to(dtype)
+        if st["unc_img"] is not None:
+            unc = ui[st["n_cond"]:].view(b, v_t, *ui.shape[1:])
+            unc[..., :lc] = nhwc(x_T).to(dtype)
+            unc[..., lc] = 1.0
+            unc[..., lc + 1:lc + 7] = nhwc(rays[:, v_c:]).to(dtype)
+        st["x_state"].copy_(nhwc(x_T).reshape(st["x_state"].shape))
+        st["step_ptr"].zero_()
+        st["timesteps"].zero_()
+        st["timesteps"][st["tgt_rows"].long()] = st["t_table"][0]
+
+    def denoise(self, ctx_latents, x_T, rays, dtype=None):
+        """the DDIM loop of `sample()` on latents: returns x_0 [b, v_t, c, hl, wl] fp32"""
+        dtype = dtype or get_compute_dtype()
+        b, v_c = ctx_latents.shape[:2]
+        v_t, hl, wl = x_T.shape[1], x_T.shape[3], x_T.shape[4]
+        n_steps = len(self.scheduler.timesteps)
+        st = self._compile(b, v_c, v_t, hl, wl, dtype, n_steps)
+        self.load_inputs(st, ctx_latents, x_T * self.scheduler.init_noise_sigma, rays, v_c)
+        for _ in range(n_steps):
+            st["plan"].replay()
+        x0 = st["x_state"].view(b, v_t, hl, wl, -1).permute(0, 1, 4, 2, 3).contiguous()
+        return x0
+
+    def sample(self, batch, x_T=None, encode_noise=None, decode: bool = True, dtype=None):
+        """diffusion_wrapper.py:455-490.  batch: {"context": {image [b,v_c,3,H,W], extrinsics, intrinsics},
+        "target": {extrinsics [b,v_t,4,4], intrinsics}}.  `x_T` / `encode_noise`: explicit noise (the
+        reference draws x_T on the CPU generator, :473)."""
+        ctx, tgt = batch["context"], batch["target"]
+        ctx_lat = self.first_stage_encode(ctx["image"], noise=encode_noise)
+        b, v_c, c, hl, wl = ctx_lat.shape
+        v_t = tgt["extrinsics"].shape[1]
+        if x_T is None:
+            x_T = torch.randn((b, v_t, c, hl, wl))
+        rays = ray_encode(ctx["extrinsics"].float(), ctx["intrinsics"].float(), tgt["extrinsics"].float(),
+                          tgt["intrinsics"].float(), hl, wl)
+        x0 = self.denoise(ctx_lat, x_T, rays, dtype)
+        return (self.last_stage_decode(x0) if decode else None), x0

@@ -1,0 +1,315 @@
+"""Host-side graph builder for the C plan executor (include/mvldm.h "Plans").
+
+A `Builder` turns module-level calls (conv, groupnorm, attention, ...) into `mvldm_op` records with
+all device pointers resolved.  Two modes share one code path:
+
+  * eager  -- every op is launched immediately through `mvldm_op_run` on the current stream (this is
+              what the diffusers-style module objects use when the reference walks them one by one);
+  * record -- ops are appended to a list; `finalize()` hands the list to `mvldm_plan_create` and
+              returns a `Plan` that runs the whole forward in C++ (optionally as one hipGraph) with
+              no Python in the loop.
+
+torch is only the allocator here (`torch.empty`) and the owner of the HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import _lib as L
+from .ops import PackedWeight, dt, ptr
+
+
+@dataclass
+class OpMeta:
+    name: str
+    kind: int
+    flops: float = 0.0        # algorithmic 2*MAC
+    bytes: float = 0.0        # algorithmic HBM bytes (compulsory reads + writes)
+
+
+class Builder:
+    def __init__(self, device, dtype: torch.dtype, record: bool = False, splitk_ws_bytes: int = 256 << 20):
+        self.device, self.dtype, self.record = torch.device(device), dtype, record
+        self.ops: List[L.Op] = []
+        self.meta: List[OpMeta] = []
+        self.keep: list = []            # tensors referenced by recorded ops
+        self._pool: dict = {}           # (numel_bytes) -> [tensors] free list for temporaries
+        self._ws = None
+        self._ws_bytes = splitk_ws_bytes
+        self._gn_ws = None
+        self._scope: List[str] = []
+
+    # ---- memory ---------------------------------------------------------------------------------
+    def empty(self, *shape, dtype=None) -> torch.Tensor:
+        dtype = dtype or self.dtype
+        if self.record:
+            nbytes = int(torch.Size(shape).numel()) * torch.empty(0, dtype=dtype).element_size()
+            free = self._pool.get(nbytes)
+            if free:
+                base = free.pop()
+                return base.view(dtype).view(*shape)
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        if self.record:
+            self.keep.append(t)
+        return t
+
+    def free(self, t: Optional[torch.Tensor]):
+        """return a temporary to the pool (record mode): later ops may overwrite it.  Execution is
+        stream-ordered in op order, so reuse after the last consumer was emitted is safe."""
+        if t is None or not self.record:
+            return
+        base = t.reshape(-1).view(torch.uint8)
+        self._pool.setdefault(base.numel(), []).append(base)
+
+    def splitk_ws(self) -> torch.Tensor:
+        if self._ws is None:
+            self._ws = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
+            self.keep.append(self._ws)
+        return self._ws
+
+    def gn_ws(self, n_img: int, groups: int) -> torch.Tensor:
+        need = n_img * L.GN_MAX_CHUNKS * groups * 16
+        if self._gn_ws is None or self._gn_ws.numel() < need:
+            self._gn_ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+            self.keep.append(self._gn_ws)
+        return self._gn_ws
+
+    # ---- bookkeeping ----------------------------------------------------------------------------
+    class _Scope:
+        def __init__(self, b, name):
+            self.b, self.name = b, name
+
+        def __enter__(self):
+            self.b._scope.append(self.name)
+
+        def __exit__(self, *a):
+            self.b._scope.pop()
+
+    def scope(self, name: str):
+        return Builder._Scope(self, name)
+
+    def _emit(self, op: L.Op, name: str, flops=0.0, nbytes=0.0, refs=()):
+        if self.record:
+            op.tag = len(self.ops)
+            self.ops.append(op)
+            self.meta.append(OpMeta("/".join(self._scope + [name]), op.kind, flops, nbytes))
+            self.keep.extend(r for r in refs if r is not None)
+        else:
+            L.check(L.load().mvldm_op_run(C.byref(op), torch.cuda.current_stream().cuda_stream))
+
+    # ---- ops ------------------------------------------------------------------------------------
+    def conv(self, x, pw: PackedWeight, bias=None, *, x2=None, stride=1, pad=None, upsample=False, row_bias=None,
+             residual=None, epilogue=L.EPI_NONE, out_dtype=None, out_scale=1.0, out=None, name="conv", splitk=0, tile=0):
+        """x (and x2): NHWC `[n, h, w, c]` contiguous; returns NHWC."""
+        n, h, w, c0 = x.shape
+        c1 = 0 if x2 is None else x2.shape[-1]
+        assert c0 + c1 == pw.c_pad, f"{name}: weight packed for {pw.c_pad} channels, got {c0}+{c1}"
+        pad = (pw.ksize // 2) if pad is None else pad
+        hs, ws_ = (2 * h, 2 * w) if upsample else (h, w)
+        if pw.ksize == 3 and stride == 2 and pad == 0:
+            ho, wo = (hs + 1 - 3) // 2 + 1, (ws_ + 1 - 3) // 2 + 1
+        else:
+            ho, wo = (hs + 2 * pad - pw.ksize) // stride + 1, (ws_ + 2 * pad - pw.ksize) // stride + 1
+        n_dst = pw.n_out // 2 if epilogue == L.EPI_GEGLU else pw.n_out
+        if out is None:
+            out = self.empty(n, ho, wo, n_dst, dtype=out_dtype or x.dtype)
+        ws = self.splitk_ws() if splitk != 1 else None
+        op = L.Op()
+        op.kind = L.OP_IGEMM
+        d = op.u.igemm
+        d.src0, d.src1, d.weight = ptr(x), ptr(x2), ptr(pw.data)
+        d.bias, d.row_bias, d.residual, d.dst = ptr(bias), ptr(row_bias), ptr(residual), ptr(out)
+        d.c0, d.c1 = c0, c1
+        d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, ho, wo
+        d.ksize, d.stride, d.pad, d.upsample = pw.ksize, stride, pad, int(upsample)
+        d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
+        d.row_bias_ld = 0 if row_bias is None else row_bias.stride(0)
+        d.epilogue, d.act_dtype, d.dst_dtype = epilogue, dt(x), dt(out)
+        d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
+        d.dst_ld = out.shape[-1] if out.shape[-1] != n_dst else 0
+        if ws is not None:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        else:
+            d.workspace, d.workspace_bytes, d.splitk = None, 0, 1
+        m = n * ho * wo
+        k_real = pw.ksize * pw.ksize * (c0 + c1)
+        es = x.element_size()
+        nbytes = (pw.n_out * k_real + n * h * w * (c0 + c1)) * es + m * n_dst * out.element_size() \
+            + (m * n_dst * es if residual is not None else 0)
+        self._emit(op, name, 2.0 * m * pw.n_out * k_real, nbytes, (x, x2, pw.data, bias, row_bias, residual, out))
+        return out
+
+    def linear(self, x, pw: PackedWeight, bias=None, *, residual=None, epilogue=L.EPI_NONE, out_dtype=None, out=None,
+               name="linear", row_bias=None):
+        """x: `[rows, c]`."""
+        rows, c = x.shape
+        y = self.conv(x.view(rows, 1, 1, c), pw, bias, residual=None if residual is None else residual.view(rows, 1, 1, -1),
+                      epilogue=epilogue, out_dtype=out_dtype, out=None if out is None else out.view(rows, 1, 1, -1),
+                      name=name, row_bias=row_bias)
+        return y.view(rows, -1)
+
+    def groupnorm(self, x, gamma, beta, groups, eps, silu, x2=None, name="groupnorm"):
+        n, c0 = x.shape[0], x.shape[-1]
+        c1 = 0 if x2 is None else x2.shape[-1]
+        hw = x.numel() // (n * c0)
+        y = self.empty(*x.shape[:-1], c0 + c1, dtype=x.dtype)
+        op = L.Op()
+        op.kind = L.OP_GROUPNORM
+        g = op.u.groupnorm
+        g.x, g.x1, g.y, g.gamma, g.beta = ptr(x), ptr(x2), ptr(y), ptr(gamma), ptr(beta)
+        g.stats_ws = self.gn_ws(n, groups).data_ptr()
+        g.n_img, g.hw, g.c0, g.c1, g.groups, g.silu, g.dtype, g.eps = n, hw, c0, c1, groups, int(silu), dt(x), eps
+        self._emit(op, name, 0.0, 3.0 * y.numel() * y.element_size(), (x, x2, y, gamma, beta))
+        return y
+
+    def layernorm(self, x, gamma, beta, eps=1e-5, name="layernorm"):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = self.empty(*x.shape, dtype=x.dtype)
+        op = L.Op()
+        op.kind = L.OP_LAYERNORM
+        l = op.u.layernorm
+        l.x, l.y, l.gamma, l.beta, l.rows, l.c, l.dtype, l.eps = ptr(x), ptr(y), ptr(gamma), ptr(beta), rows, c, dt(x), eps
+        self._emit(op, name, 0.0, 2.0 * y.numel() * y.element_size(), (x, y, gamma, beta))
+        return y
+
+    def attention(self, q, k, v, heads, head_dim, seg, q_lens, kv_lens, scale=None, name="attention"):
+        """q/k/v: 2-D views with unit column stride (may be slices of one fused projection)."""
+        assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+        out = self.empty(q.shape[0], heads * head_dim, dtype=q.dtype)
+        op = L.Op()
+        op.kind = L.OP_ATTENTION
+        a = op.u.attention
+        a.q, a.k, a.v, a.out, a.seg = ptr(q), ptr(k), ptr(v), ptr(out), ptr(seg)
+        a.ld_q, a.ld_k, a.ld_v, a.ld_o = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+        a.heads, a.head_dim, a.n_seg, a.max_q_len, a.dtype = heads, head_dim, seg.shape[0], max(q_lens), dt(q)
+        a.scale = head_dim ** -0.5 if scale is None else scale
+        pairs = sum(ql * kl for ql, kl in zip(q_lens, kv_lens))
+        es = q.element_size()
+        nbytes = (sum(q_lens) * 2 + sum(kv_lens) * 2) * heads * head_dim * es
+        self._emit(op, name, 4.0 * pairs * heads * head_dim, nbytes, (q, k, v, out, seg))
+        return out
+
+    def timestep_embed(self, timesteps, freqs, dim, flip, dtype, name="time_proj"):
+        out = self.empty(timesteps.numel(), dim, dtype=dtype)
+        op = L.Op()
+        op.kind = L.OP_TIMESTEP_EMBED
+        t = op.u.temb
+        t.timesteps, t.freqs, t.out, t.n, t.dim, t.flip, t.dst_dtype = ptr(timesteps), ptr(freqs), ptr(out), timesteps.numel(), dim, int(flip), dt(out)
+        self._emit(op, name, 0.0, out.numel() * out.element_size(), (timesteps, freqs, out))
+        return out
+
+    def eltwise(self, x, op_code, out_dtype=None, name="eltwise"):
+        y = self.empty(*x.shape, dtype=out_dtype or x.dtype)
+        op = L.Op()
+        op.kind = L.OP_ELTWISE
+        e = op.u.eltwise
+        e.x, e.y, e.n, e.op, e.src_dtype, e.dst_dtype = ptr(x), ptr(y), x.numel(), op_code, dt(x), dt(y)
+        self._emit(op, name, 0.0, x.numel() * (x.element_size() + y.element_size()), (x, y))
+        return y
+
+    def ddim_step(self, eps, x_t, x_next, cond_img, uncond_img, cfg_scale, coef, step_ptr, unet_in, name="ddim_cfg_step"):
+        n_tgt, h, w, c = x_t.shape
+        op = L.Op()
+        op.kind = L.OP_DDIM_STEP
+        d = op.u.ddim
+        d.eps, d.x_t, d.x_next, d.cond_img, d.uncond_img = ptr(eps), ptr(x_t), ptr(x_next), ptr(cond_img), ptr(uncond_img)
+        d.coef, d.step_ptr, d.unet_in = ptr(coef), ptr(step_ptr), ptr(unet_in)
+        d.n_tgt, d.hw, d.c, d.cfg_scale = n_tgt, h * w, c, cfg_scale
+        d.unet_in_c = 0 if unet_in is None else unet_in.shape[-1]
+        d.unet_in_dtype = L.F32 if unet_in is None else dt(unet_in)
+        self._emit(op, name, 0.0, 5.0 * x_t.numel() * 4, (eps, x_t, x_next, cond_img, uncond_img, coef, step_ptr, unet_in))
+        return x_next
+
+    def ddim_advance(self, step_ptr, t_table, timesteps, tgt_rows, name="ddim_advance"):
+        op = L.Op()
+        op.kind = L.OP_DDIM_ADVANCE
+        a = op.u.advance
+        a.step_ptr, a.t_table, a.timesteps, a.tgt_rows = ptr(step_ptr), ptr(t_table), ptr(timesteps), ptr(tgt_rows)
+        a.n_steps, a.n_rows = t_table.numel(), 0 if tgt_rows is None else tgt_rows.numel()
+        self._emit(op, name, 0.0, 0.0, (step_ptr, t_table, timesteps, tgt_rows))
+
+    def memcpy(self, dst, src, name="memcpy"):
+        assert dst.is_contiguous() and src.is_contiguous() and dst.numel() * dst.element_size() == src.numel() * src.element_size()
+        op = L.Op()
+        op.kind = L.OP_MEMCPY
+        op.u.memcpy_.src, op.u.memcpy_.dst, op.u.memcpy_.bytes = ptr(src), ptr(dst), src.numel() * src.element_size()
+        self._emit(op, name, 0.0, 2.0 * src.numel() * src.element_size(), (dst, src))
+
+    def nhwc_to_nchw(self, src, dst, c=None, c_off=0, scale=1.0, shift=0.0, clamp01=False, name="nhwc_to_nchw"):
+        n, h, w, sc = src.shape
+        op = L.Op()
+        op.kind = L.OP_NHWC_TO_NCHW
+        l = op.u.layout
+        l.src, l.dst, l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype = ptr(src), ptr(dst), n, c or sc, h * w, sc, c_off, dt(src)
+        l.clamp01, l.scale, l.shift = int(clamp01), scale, shift
+        self._emit(op, name, 0.0, src.numel() * src.element_size() + dst.numel() * 4, (src, dst))
+        return dst
+
+    def nchw_to_nhwc(self, src, dst, c_off=0, name="nchw_to_nhwc"):
+        n, c, h, w = src.shape
+        op = L.Op()
+        op.kind = L.OP_NCHW_TO_NHWC
+        l = op.u.layout
+        l.src, l.dst, l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype = ptr(src), ptr(dst), n, c, h * w, dst.shape[-1], c_off, dt(dst)
+        self._emit(op, name, 0.0, src.numel() * 4 + dst.numel() * dst.element_size(), (src, dst))
+        return dst
+
+    # ---- finish ---------------------------------------------------------------------------------
+    def finalize(self) -> "Plan":
+        assert self.record
+        return Plan(self.ops, self.meta, self.keep, self.device)
+
+
+class Plan:
+    """A recorded op list living in the C executor.  Holds references to every tensor it touches."""
+
+    def __init__(self, ops, meta, keep, device):
+        self.meta, self._keep, self.device = list(meta), list(keep), device
+        arr = (L.Op * max(len(ops), 1))(*ops)
+        h = C.c_void_p()
+        L.check(L.load().mvldm_plan_create(arr, len(ops), C.byref(h)))
+        self._h = h
+        self._stream = None
+        self.captured = False
+
+    def __len__(self):
+        return len(self.meta)
+
+    @staticmethod
+    def _cur():
+        return torch.cuda.current_stream().cuda_stream
+
+    def run(self, first: int = 0, last: Optional[int] = None):
+        last = len(self.meta) if last is None else last
+        L.check(L.load().mvldm_plan_run_range(self._h, first, last, self._cur()))
+
+    def capture(self):
+        """record the plan into a hipGraph on a private stream"""
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        self._stream.wait_stream(torch.cuda.current_stream())
+        L.check(L.load().mvldm_plan_capture(self._h, self._stream.cuda_stream))
+        torch.cuda.current_stream().wait_stream(self._stream)
+        self.captured = True
+
+    def replay(self):
+        L.check(L.load().mvldm_plan_replay(self._h, self._cur()))
+
+    def profile(self, iters: int = 3):
+        """per-op average milliseconds (hipEvents on the launch stream, eager launches)"""
+        out = (C.c_float * max(len(self.meta), 1))()
+        L.check(L.load().mvldm_plan_profile(self._h, self._cur(), iters, out))
+        return [float(v) for v in out[:len(self.meta)]]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.load().mvldm_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

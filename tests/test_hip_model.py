@@ -1,0 +1,201 @@
+"""GPU parity tests at block / model / pipeline level (through the drop-in module surface and the
+C-side plans) against (a) the committed golden vectors produced by the REFERENCE's own code and
+(b) the CPU oracle on seeded inputs.
+
+Tolerances (relative L2 of the output tensor vs the fp32 reference / oracle):
+    f32 path  : 2e-4 per block, 1e-3 through a whole UNet forward / DDIM loop  (north star: latents
+                within 1e-3 rel-err of the reference path)
+    bf16 path : 3e-2 per block / forward (8-bit mantissa storage between ~300 chained ops)
+    f16 path  : 4e-3 per block / forward
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from seeded import load_seeded, random_cameras
+
+pytestmark = pytest.mark.gpu
+
+TOL_BLOCK = {torch.float32: 2e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}
+TOL_MODEL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+IDS = ["f32", "bf16", "f16"]
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mv_ldm_amd
+    from mv_ldm_amd import _lib
+    _lib.load()
+    return mv_ldm_amd
+
+
+def sd_cfg(M, widths):
+    from mv_ldm_amd.mvunet import MultiViewUNetCfg, UNet2DModelCfg
+    over = dict(block_out_channels=tuple(widths), attention_head_dim=tuple(max(1, c // 64) for c in widths))
+    return MultiViewUNetCfg(autoencoder=UNet2DModelCfg(block_out_channels=tuple(widths)),
+                            pretrained_from="stabilityai/stable-diffusion-2-1", pretrained_overrides=over)
+
+
+def scratch_cfg(M, widths):
+    from mv_ldm_amd.mvunet import MultiViewUNetCfg, UNet2DModelCfg
+    return MultiViewUNetCfg(autoencoder=UNet2DModelCfg(block_out_channels=tuple(widths)), pretrained_from=None)
+
+
+# ------------------------------------------------------------------------------------------------ G1
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_spatial_transformer_3d_vs_reference_golden(M, golden, dtype):
+    """G1: outputs of the reference's own SpatialTransformer3D (mvdream/attention.py:371-439)"""
+    from mv_ldm_amd.mvunet import SpatialTransformer3D, SpatialTransformer3DCfg
+    g = golden("g1_spatial_transformer_3d")
+    for i in range(int(g["n"])):
+        C, V, h, w, b, seed = (int(v) for v in g[f"c{i}_meta"])
+        m = SpatialTransformer3D(SpatialTransformer3DCfg(num_heads=8), C)
+        cs = load_seeded(m, seed)
+        assert abs(cs - float(g[f"c{i}_checksum"])) <= 1e-9 * cs
+        m = m.cuda()
+        with M.compute_dtype(dtype):
+            y = m(torch.from_numpy(g[f"c{i}_x"]).cuda())
+        assert y.shape == g[f"c{i}_y"].shape
+        e = rel_err(y.float().cpu(), g[f"c{i}_y"])
+        assert e < TOL_BLOCK[dtype], (i, e)
+
+
+# ------------------------------------------------------------------------------------------------ G4
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_mvunet_forward_vs_reference_golden(M, golden, dtype):
+    """G4: the reference's MultiViewUNet.forward walk (mvunet.py:90-208); fused plan AND the literal
+    module-by-module walk."""
+    from mv_ldm_amd.mvunet import MultiViewUNet
+    g = golden("g4_mvunet_forward")
+    ran = 0
+    for i in range(int(g["n"])):
+        topo, widths = str(g[f"c{i}_topology"]), [int(v) for v in g[f"c{i}_widths"]]
+        if widths[0] // 8 % (4 if dtype == torch.float32 else 8):
+            continue  # multi-view head dim 4: below the 16-byte chunk of the 16-bit paths
+        m = MultiViewUNet(sd_cfg(M, widths) if topo == "sd" else scratch_cfg(M, widths), 11, 4)
+        assert len(m.state_dict()) == int(g[f"c{i}_nkeys"])
+        cs = load_seeded(m, int(g[f"c{i}_seed"]))
+        assert abs(cs - float(g[f"c{i}_checksum"])) <= 1e-9 * cs
+        m = m.cuda()
+        x, t = torch.from_numpy(g[f"c{i}_x"]).cuda(), torch.from_numpy(g[f"c{i}_t"]).cuda()
+        with M.compute_dtype(dtype):
+            y = m(x, t)
+            yw = m.forward_walk(x, t)
+        e, ew = rel_err(y.cpu(), g[f"c{i}_y"]), rel_err(yw.cpu(), g[f"c{i}_y"])
+        assert e < TOL_MODEL[dtype] and ew < TOL_MODEL[dtype], (i, topo, e, ew)
+        ran += 1
+    assert ran >= 3
+
+
+def test_mvunet_scratch_topology_f32(M, golden):
+    """scratch UNet cases of G4 (multi-view head dim 4/8/16): fp32 path"""
+    from mv_ldm_amd.mvunet import MultiViewUNet
+    g = golden("g4_mvunet_forward")
+    for i in range(int(g["n"])):
+        if str(g[f"c{i}_topology"]) != "scratch":
+            continue
+        m = MultiViewUNet(scratch_cfg(M, [int(v) for v in g[f"c{i}_widths"]]), 11, 4)
+        load_seeded(m, int(g[f"c{i}_seed"]))
+        m = m.cuda()
+        with M.compute_dtype(torch.float32):
+            y = m(torch.from_numpy(g[f"c{i}_x"]).cuda(), torch.from_numpy(g[f"c{i}_t"]).cuda())
+        assert rel_err(y.cpu(), g[f"c{i}_y"]) < TOL_MODEL[torch.float32]
+
+
+# ------------------------------------------------------------------------------------------------ G5
+def _pipeline(M, g, p, dtype):
+    from mv_ldm_amd.mvunet import MultiViewUNet
+    from mv_ldm_amd.pipeline import MVLDMPipeline, SamplerCfg
+    from mv_ldm_amd.scheduler import DDIMScheduler
+    from mv_ldm_amd.vae import AutoencoderKL
+    widths = [int(v) for v in g["widths"]]
+    den = MultiViewUNet(sd_cfg(M, widths), 11, 4)
+    vae = AutoencoderKL.from_pretrained("x", config_overrides=dict(block_out_channels=tuple(int(v) for v in g["vae_widths"]),
+                                                                   layers_per_block=1))
+    assert abs(load_seeded(den, 400) - float(g[p + "checksum_denoiser"])) < 1e-6
+    assert abs(load_seeded(vae, 401) - float(g[p + "checksum_vae"])) < 1e-6
+    sch = DDIMScheduler(clip_sample=False)
+    pipe = MVLDMPipeline(den.cuda(), vae.cuda(), sch, SamplerCfg(use_cfg=bool(g[p + "use_cfg"]), cfg_scale=3.0,
+                                                                 num_inference_steps=5))
+    pipe.set_timesteps(5)
+    return pipe
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_step_and_sample_vs_reference_golden(M, golden, dtype):
+    """G5: DiffusionWrapper.step / .sample of the reference (diffusion_wrapper.py:413-490), 5 DDIM
+    steps, with and without classifier-free guidance, explicit noise."""
+    from mv_ldm_amd.pipeline import ray_encode
+    g = golden("g5_step_sample")
+    for ci in range(int(g["n"])):
+        p = f"c{ci}_"
+        with M.compute_dtype(dtype):
+            pipe = _pipeline(M, g, p, dtype)
+            extr, intr = torch.from_numpy(g[p + "extr"]), torch.from_numpy(g[p + "intr"])
+            v_c = g[p + "ctx_img"].shape[1]
+            batch = {"context": {"image": torch.from_numpy(g[p + "ctx_img"]), "extrinsics": extr[:, :v_c], "intrinsics": intr[:, :v_c]},
+                     "target": {"extrinsics": extr[:, v_c:], "intrinsics": intr[:, v_c:]}}
+            img, x0 = pipe.sample(batch, x_T=torch.from_numpy(g[p + "x_T"]), encode_noise=torch.from_numpy(g[p + "enc_noise"]))
+            e_img = rel_err(img.cpu(), g[p + "img"])
+            # the literal two-forward step of the reference on the drop-in modules
+            ctx_lat, x_t = torch.from_numpy(g[p + "step_ctx_lat"]).cuda(), torch.from_numpy(g[p + "step_x_t"]).cuda()
+            hl = x_t.shape[-1]
+            rays = ray_encode(extr[:, :v_c], intr[:, :v_c], extr[:, v_c:], intr[:, v_c:], hl, hl)
+            assert rel_err(rays, g[p + "rays"]) < 1e-6
+            ctx_in = torch.cat([ctx_lat, torch.zeros_like(ctx_lat[:, :, :1])], dim=2)
+            x_prev = pipe.step(pipe.denoiser, x_t, torch.tensor(int(g[p + "step_ts"])), ctx_in, rays.cuda(),
+                               torch.ones_like(x_t[:, :, :1]))
+            e_step = rel_err(x_prev.cpu(), g[p + "step_x_prev"])
+        assert e_step < TOL_MODEL[dtype], (ci, "step", e_step)
+        assert e_img < 2 * TOL_MODEL[dtype], (ci, "sample", e_img)
+
+
+# ------------------------------------------------------------------------------------------------ VAE vs oracle
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_vae_decode_encode_vs_oracle(M, dtype):
+    from mv_ldm_amd.vae import AutoencoderKL
+    from oracle.vae import AutoencoderKL as OracleVAE
+    over = dict(block_out_channels=(32, 64, 64), layers_per_block=2)
+    v, o = AutoencoderKL.from_pretrained("x", config_overrides=over), OracleVAE.from_pretrained("x", config_overrides=over).eval()
+    load_seeded(v, 7)
+    load_seeded(o, 7)
+    v = v.cuda()
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(1))
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    with M.compute_dtype(dtype):
+        dec = v.decode(z.cuda()).sample
+        enc = v.encode(img.cuda()).latent_dist
+    assert dec.shape == (2, 3, 32, 32)
+    assert rel_err(dec.cpu(), o.decode(z).sample) < TOL_MODEL[dtype]
+    ref = o.encode(img).latent_dist
+    assert rel_err(enc.mean.cpu(), ref.mean) < TOL_MODEL[dtype]
+    assert rel_err(enc.std.cpu(), ref.std) < TOL_MODEL[dtype]
+
+
+# ------------------------------------------------------------------------------------------------ real topology
+def test_full_sd21_topology_bf16_vs_oracle(M):
+    """The real config-2 network (SD-2.1 widths 320/640/1280/1280, heads 5/10/20/20 x 64, multi-view heads
+    8 x 40/80/160; 1.07 B parameters) at a small latent (16x16, 3 views: 1 context + 2 targets):
+    fused bf16 plan vs the fp32 CPU oracle."""
+    from mv_ldm_amd.mvunet import MultiViewUNet, MultiViewUNetCfg, UNet2DModelCfg
+    from oracle import multiview as MV
+    cfg = MultiViewUNetCfg(autoencoder=UNet2DModelCfg(), pretrained_from="stabilityai/stable-diffusion-2-1")
+    m = MultiViewUNet(cfg, 11, 4)
+    o = MV.MultiViewUNet(MV.MVUNetCfg(pretrained_from="stabilityai/stable-diffusion-2-1"), 11, 4).eval()
+    assert sorted(m.state_dict()) == sorted(o.state_dict())
+    sd = __import__("seeded").seeded_state(o, 11)
+    o.load_state_dict(sd)
+    m.load_state_dict(sd)
+    del sd
+    m = m.cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, 11, 16, 16, generator=g)
+    t = torch.tensor([[0, 500, 500]])
+    ref = o(x, t)
+    with M.compute_dtype(torch.bfloat16):
+        y = m(x.cuda(), t.cuda())
+    e = rel_err(y.cpu(), ref)
+    assert e < TOL_MODEL[torch.bfloat16], e
