@@ -74,6 +74,7 @@ typedef struct mvldm_igemm_desc {
     int32_t dst_dtype;  /* act_dtype or MVLDM_F32 */
     int32_t splitk;     /* >= 1; 0 = let the library choose (needs workspace) */
     int32_t tile;       /* 0 = auto; else force a tile config (tests / tuning) */
+    int32_t k_order;    /* K order of the packed weight: 0 = (tap, channel); 1 = (64-channel block, tap, channel) */
     int32_t dst_ld;     /* row stride of dst in elements; 0 = n_dst (dense).  > n_dst writes into a wider buffer */
     float out_scale;
     size_t workspace_bytes;
@@ -84,10 +85,12 @@ size_t mvldm_igemm_workspace_bytes(const mvldm_igemm_desc* d);
 
 /* Pack a PyTorch-layout fp32 weight ([n_out][c_in][k][k] conv or [n_out][c_in] linear) into the
  * kernel layout: dst[n'][ (ky*k+kx)*c_pad + c ], zero padded to [n_pad][k_pad]; `geglu` != 0
- * interleaves rows n and n + n_out/2 in blocks of 32.  replaces: nothing in the reference (weights
+ * interleaves rows n and n + n_out/2 in blocks of 32; `k_order` 1 stores k as (channel block of 64 [32 for
+ * f32], tap, channel in block) so that the 9 taps of one channel block are consecutive K-tiles (their
+ * activation reads hit L2 instead of crossing the fabric 9 times); needs c_pad % 64 == 0.  replaces: nothing in the reference (weights
  * there stay in torch layout); this is the one-time load-time transform. */
 int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksize, int c_pad, int n_pad,
-                      int k_pad, int geglu, int dst_dtype, mvldm_stream_t stream);
+                      int k_pad, int geglu, int k_order, int dst_dtype, mvldm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.   replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D

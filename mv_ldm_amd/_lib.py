@@ -30,7 +30,7 @@ class IgemmDesc(C.Structure):
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
                 ("n_out", i32), ("n_pad", i32), ("k_pad", i32),
                 ("row_bias_ld", i32), ("epilogue", i32), ("act_dtype", i32), ("dst_dtype", i32),
-                ("splitk", i32), ("tile", i32), ("dst_ld", i32), ("out_scale", f32), ("workspace_bytes", sz)]
+                ("splitk", i32), ("tile", i32), ("k_order", i32), ("dst_ld", i32), ("out_scale", f32), ("workspace_bytes", sz)]
 
 
 class _GroupNorm(C.Structure):
@@ -93,7 +93,7 @@ SIGNATURES = {
     "mvldm_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(sz), C.c_char_p, C.c_int]),
     "mvldm_igemm_fwd": (C.c_int, [C.POINTER(IgemmDesc), vp]),
     "mvldm_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
-    "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 8 + [vp]),
+    "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 9 + [vp]),
     "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp]),
     "mvldm_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
     "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp]),

@@ -15,6 +15,7 @@
 // Workgroup -> tile mapping is XCD-aware: each of the 8 XCDs owns a contiguous range of
 // (split, n-tile, m-tile) ids with m fastest, so one weight tile is streamed from HBM by one XCD only.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -31,6 +32,8 @@ struct IgemmParams {
     float out_scale;
     int splitk, k_tiles, k_tiles_per_split;
     int tiles_m, tiles_n;
+    int korder;                 // 0: k = (tap, channel)   1: k = (channel block of BK, tap, channel in block)
+    int px, sub_m, sub_n, m_fast;  // XCD-aware 2-D tile partition
 };
 
 // ---- per-dtype MFMA + LDS policy -------------------------------------------------------------------
@@ -93,6 +96,84 @@ __device__ __forceinline__ void epilogue_store(const IgemmParams& p, int m, int 
     else reinterpret_cast<T*>(p.dst)[o] = from_f32<T>(v);
 }
 
+// Workgroup -> (split, m-tile, n-tile).  The hardware places workgroup b on XCD b % 8 (observed; used for
+// speed only): the 8 XCDs form a px x py grid over the tile space so that each XCD's private 4 MB L2
+// sees one slice of A and one slice of W -- the host picks (px, py) minimising py*bytes(A) + px*bytes(W),
+// the traffic that crosses the fabric.  Inside an XCD, tiles that share the larger operand are adjacent.
+__device__ __forceinline__ bool map_block(const IgemmParams& p, int& split, int& tm, int& tn) {
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int xm = xcd % p.px, xn = xcd / p.px;
+    const int per = p.sub_m * p.sub_n;
+    split = idx / per;
+    const int r = idx - split * per;
+    int tml, tnl;
+    if (p.m_fast) { tnl = r / p.sub_m; tml = r - tnl * p.sub_m; }
+    else { tml = r / p.sub_n; tnl = r - tml * p.sub_n; }
+    tm = xm * p.sub_m + tml;
+    tn = xn * p.sub_n + tnl;
+    return tm < p.tiles_m && tn < p.tiles_n;
+}
+
+// ---- epilogue shared by both main-loop variants ---------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tm, int tn,
+                                               int split, int wm, int wn, int hi, int l31) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
+    if (p.splitk > 1) {
+        float* ws = p.ws + (size_t)split * p.M * p.n_pad;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = tn * BN + wn * (BN / WN) + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m < p.M && n < p.n_pad) ws[(size_t)m * p.n_pad + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (geglu) {
+            if constexpr (TN % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int nb = tn * BN + wn * (BN / WN) + j * 32;  // packed col of the value block
+                    const int col = (nb >> 6) * 32 + l31;             // output column
+                    if (col >= p.n_dst) continue;
+                    const float bv = p.bias ? p.bias[col] : 0.f;
+                    const float bg = p.bias ? p.bias[p.n_dst + col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (m >= p.M) continue;
+                        epilogue_store<T>(p, m, col, (acc[i][j][r] + bv) * gelu_erf_f(acc[i][j + 1][r] + bg));
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = tn * BN + wn * (BN / WN) + j * 32 + l31;
+                if (n >= p.n_out) continue;
+                const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m >= p.M) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (p.row_bias) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
+                    if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
+                    epilogue_store<T>(p, m, n, v);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p) {
     using M_ = Mma<T>;
@@ -109,11 +190,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5, l31 = lane & 31;
 
-    const int ntile = p.tiles_m * p.tiles_n;
-    int lid = xcd_remap(blockIdx.x, ntile * p.splitk);
-    const int split = lid / ntile;
-    lid -= split * ntile;
-    const int tn = lid / p.tiles_m, tm = lid - tn * p.tiles_m;
+    int split, tm, tn;
+    if (!map_block(p, split, tm, tn)) return;   // uniform per workgroup, before any barrier
     const int kt0 = split * p.k_tiles_per_split;
     const int kt1 = min(kt0 + p.k_tiles_per_split, p.k_tiles);
 
@@ -138,9 +216,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
 
     u32x4 areg[A_IT], breg[B_IT];
     auto load_tile = [&](int kt) {
-        const int ke = kt * BK + kc * EPC;
-        const int tap = ke / p.ctot;
-        const int c = ke - tap * p.ctot;
+        int tap, c;
+        if (p.korder) {
+            const int cb = kt / p.taps;
+            tap = kt - cb * p.taps;
+            c = cb * BK + kc * EPC;
+        } else {
+            const int ke = kt * BK + kc * EPC;
+            tap = ke / p.ctot;
+            c = ke - tap * p.ctot;
+        }
         const bool tap_ok = tap < p.taps;
         const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
         const bool from0 = c < p.c0;
@@ -213,60 +298,189 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
         cur ^= 1;
     }
 
-    // ---- epilogue ----
-    const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
-    if (p.splitk > 1) {
-        float* ws = p.ws + (size_t)split * p.M * p.n_pad;
+    igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
+}
+
+// ---- 16-bit main loop: LDS-DMA ring -----------------------------------------------------------------
+// Same tiles, same LDS image, same MFMA consumption as igemm_kernel, but the K-tiles arrive by
+// `global_load_lds_dwordx4` (HBM/L2 -> LDS without touching VGPRs) into a ring of STAGES buffers with
+// STAGES-1 tiles in flight, so a workgroup no longer pays one global-memory latency per K-tile (the
+// 1-deep register prefetch did: ~1.5 us x K/64 per output tile).  One `s_barrier` per K-tile:
+//     wait (counted vmcnt) for MY pieces of tile t  ->  barrier  ->  issue tile t+STAGES-1 into the
+//     slot everybody just finished reading  ->  MFMAs on tile t.
+// The DMA writes LDS lane-linearly (wave base + lane*16), so the XOR swizzle of the LDS image is
+// applied to the per-lane SOURCE address instead (chunk = slot ^ ((row>>1)&7)); padding taps, rows
+// beyond M / n_pad and tiles past the K range read a 16-byte zero page.  Every iteration issues
+// exactly LPT pieces per wave, which keeps the `vmcnt` arithmetic uniform to the end of the loop.
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_async_kernel(const IgemmParams p) {
+    using M_ = Mma<T>;
+    static_assert(sizeof(T) == 2, "LDS-DMA main loop is for the 16-bit activation types");
+    constexpr int NW = WM * WN;
+    constexpr int BK = 64, EPC = 8;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;     // 1-KiB pieces (8 rows) per wave per tile
+    constexpr int LPT = A_IT + B_IT;
+    static_assert(A_IT >= 1 && B_IT >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "bad tile");
+    static_assert((STAGES - 2) * LPT <= 63, "vmcnt immediate");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    int split, tm, tn;
+    if (!map_block(p, split, tm, tn)) return;   // uniform per workgroup, before any barrier
+    const int kt0 = split * p.k_tiles_per_split;
+    const int kt1 = min(kt0 + p.k_tiles_per_split, p.k_tiles);
+
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    const int slot = lane & 7, rsub = lane >> 3;
+
+    // ---- A pieces: this lane's output pixel and a running (ky, kx, channel) cursor per piece ----
+    // (all index math is 32-bit and branch-free: it competes with the MFMAs for issue slots)
+    int a_pix0[A_IT], a_y[A_IT], a_x[A_IT], a_ky[A_IT], a_kx[A_IT], a_c[A_IT];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = tn * BN + wn * (BN / WN) + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (m < p.M && n < p.n_pad) ws[(size_t)m * p.n_pad + n] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        if (geglu) {
-            if constexpr (TN % 2 == 0) {
-#pragma unroll
-                for (int j = 0; j < TN; j += 2) {
-                    const int nb = tn * BN + wn * (BN / WN) + j * 32;  // packed col of the value block
-                    const int col = (nb >> 6) * 32 + l31;             // output column
-                    if (col >= p.n_dst) continue;
-                    const float bv = p.bias ? p.bias[col] : 0.f;
-                    const float bg = p.bias ? p.bias[p.n_dst + col] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (m >= p.M) continue;
-                        epilogue_store<T>(p, m, col, (acc[i][j][r] + bv) * gelu_erf_f(acc[i][j + 1][r] + bg));
-                    }
-                }
-            }
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (wave + NW * it) * 8 + rsub;
+        const int m = tm * BM + row;
+        if (m < p.M) {
+            const int img = m / p.hw_out, rem = m - img * p.hw_out;
+            const int oy = rem / p.w_out;
+            a_pix0[it] = img * p.h_in;
+            a_y[it] = oy * p.stride - p.pad;
+            a_x[it] = (rem - oy * p.w_out) * p.stride - p.pad;
         } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = tn * BN + wn * (BN / WN) + j * 32 + l31;
-                if (n >= p.n_out) continue;
-                const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (m >= p.M) continue;
-                    float v = acc[i][j][r] + bv;
-                    if (p.row_bias) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
-                    if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
-                    epilogue_store<T>(p, m, n, v);
-                }
-            }
+            a_pix0[it] = 0; a_y[it] = -(1 << 20); a_x[it] = 0;   // always out of bounds -> zero page
+        }
+        const int kc = slot ^ ((row >> 1) & 7);
+        if (p.korder) {
+            a_c[it] = kc * EPC; a_ky[it] = 0; a_kx[it] = 0;   // chunk offset inside the 64-channel block
+        } else {
+            const int ke = kt0 * BK + kc * EPC;
+            const int tap = ke / p.ctot;
+            a_c[it] = ke - tap * p.ctot;
+            a_ky[it] = tap / p.ksize;
+            a_kx[it] = tap - a_ky[it] * p.ksize;
         }
     }
+    // ---- B pieces: weight row pointer (already offset to this lane's swizzled chunk) ----
+    const T* b_ptr[B_IT];
+    int b_step[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int row = (wave + NW * it) * 8 + rsub;
+        const int n = tn * BN + row;
+        const int kc = slot ^ ((row >> 1) & 7);
+        const bool ok = n < p.n_pad;
+        b_ptr[it] = ok ? reinterpret_cast<const T*>(p.weight) + (size_t)n * p.k_pad + (size_t)kt0 * BK + kc * EPC : zero;
+        b_step[it] = ok ? BK : 0;
+    }
+    const unsigned hs = p.upsample ? 2 * p.h_in : p.h_in, wsz = p.upsample ? 2 * p.w_in : p.w_in;
+    const int ups = p.upsample ? 1 : 0;
+    const T* s0 = reinterpret_cast<const T*>(p.src0);
+    const T* s1 = reinterpret_cast<const T*>(p.src1);
+
+    int kt_issue = kt0;   // K-tile index of the next issue (korder 1 derives tap / channel block from it)
+    auto issue_tile = [&](int stage, bool live) {
+        char* at = smem + stage * STAGE_BYTES;
+        char* bt = at + A_BYTES;
+        // korder 1: the whole K-tile is ONE tap and ONE 64-channel block of ONE source -> scalar decode
+        int u_ky = 0, u_kx = 0, u_cs = 0;
+        const T* u_base = zero;
+        if (p.korder && live) {
+            const int cb = kt_issue / p.taps, tap = kt_issue - cb * p.taps;
+            u_ky = tap / p.ksize;
+            u_kx = tap - u_ky * p.ksize;
+            const int c = cb * BK;
+            const bool from0 = c < p.c0;
+            u_cs = from0 ? p.c0 : p.c1;
+            u_base = from0 ? s0 + c : s1 + (c - p.c0);
+        }
+        ++kt_issue;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const T* src = zero;
+            if (live && p.korder) {
+                const int iy = a_y[it] + u_ky, ix = a_x[it] + u_kx;
+                const bool ok = (unsigned)iy < hs && (unsigned)ix < wsz;
+                const unsigned pix = (unsigned)(a_pix0[it] + (iy >> ups)) * (unsigned)p.w_in + (unsigned)(ix >> ups);
+                const T* ptr = u_base + (pix * (unsigned)u_cs + (unsigned)a_c[it]);
+                src = ok ? ptr : zero;
+            } else if (live) {
+                const int c = a_c[it];
+                const int iy = a_y[it] + a_ky[it], ix = a_x[it] + a_kx[it];
+                const bool ok = a_ky[it] < p.ksize && (unsigned)iy < hs && (unsigned)ix < wsz;
+                const unsigned pix = (unsigned)(a_pix0[it] + (iy >> ups)) * (unsigned)p.w_in + (unsigned)(ix >> ups);
+                const bool from0 = c < p.c0;
+                const unsigned off = from0 ? pix * (unsigned)p.c0 + (unsigned)c : pix * (unsigned)p.c1 + (unsigned)(c - p.c0);
+                const T* ptr = (from0 ? s0 : s1) + off;
+                src = ok ? ptr : zero;
+                // advance the cursor by one K-tile
+                int nc = c + BK, kx = a_kx[it], ky = a_ky[it];
+                while (nc >= p.ctot) {
+                    nc -= p.ctot;
+                    if (++kx == p.ksize) { kx = 0; ++ky; }
+                }
+                a_c[it] = nc; a_kx[it] = kx; a_ky[it] = ky;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const T* src = zero;
+            if (live) {
+                src = b_ptr[it];
+                b_ptr[it] += b_step[it];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(bt + (wave + NW * it) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: STAGES-1 tiles in flight
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue_tile(s, kt0 + s < kt1);
+
+    int st_c = 0, st_l = STAGES - 1;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // my pieces of tile kt have landed once at most (STAGES-2) newer tiles' pieces are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        __builtin_amdgcn_s_barrier();   // everybody's pieces landed; everybody finished reading slot st_l
+        issue_tile(st_l, kt + STAGES - 1 < kt1);
+        const char* at = smem + st_c * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / M_::KI; ++kk) {
+            typename M_::Frag a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+        }
+        st_c = st_c + 1 == STAGES ? 0 : st_c + 1;
+        st_l = st_l + 1 == STAGES ? 0 : st_l + 1;
+    }
+    // drain the (dummy) pieces still in flight before this workgroup's LDS can be handed to another one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
 }
 
 // split-K: sum the fp32 partial slabs and run the same epilogue (deterministic, no atomics)
@@ -301,11 +515,20 @@ template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce
 // ---- weight packing -------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_out,
-                                                          int c_in, int ksize, int c_pad, int n_pad, int k_pad, int geglu) {
+                                                          int c_in, int ksize, int c_pad, int n_pad, int k_pad, int geglu, int korder, int bk) {
     const size_t total = (size_t)n_pad * k_pad;
+    const int taps = ksize * ksize;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int np = (int)(idx / k_pad), k = (int)(idx - (size_t)np * k_pad);
-        const int tap = k / c_pad, c = k - tap * c_pad;
+        int tap, c;
+        if (korder) {
+            const int kt = k / bk, cb = kt / taps;
+            tap = kt - cb * taps;
+            c = cb * bk + (k - kt * bk);
+        } else {
+            tap = k / c_pad;
+            c = k - tap * c_pad;
+        }
         const int n = orig_col(np, n_out, geglu != 0);
         float v = 0.f;
         if (n < n_out && tap < ksize * ksize && c < c_in)
@@ -319,18 +542,58 @@ struct TileCfg { int bm, bn, threads; };
 static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64, 128, 256}, {64, 64, 128}, {32, 64, 64}};
 constexpr int kNumTiles = 5;
 
-template <typename T, int BM, int BN, int WM, int WN> static int launch_tile(const IgemmParams& p, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * Mma<T>::PITCH;
-    auto kern = igemm_kernel<T, BM, BN, WM, WN>;
-    static bool attr_done = false;
+// tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
+// target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static const int kEnvStages = env_int("MVLDM_IGEMM_STAGES", 0);
+static const int kEnvTarget = env_int("MVLDM_IGEMM_TARGET", 0);
+static const int kEnvSync = env_int("MVLDM_IGEMM_SYNC", 0);
+static const int kEnvPx = env_int("MVLDM_IGEMM_PX", 0);
+
+template <typename KernT> static int launch_kernel(KernT kern, bool& attr_done, int smem, int blocks, int threads,
+                                                   const IgemmParams& p, hipStream_t s) {
     if (!attr_done) {
         if (smem > 48 * 1024)
             MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * p.splitk), dim3(WM * WN * 64), smem, s, p);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), smem, s, p);
     return check_launch();
+}
+
+template <typename T, int BM, int BN, int WM, int WN> static int launch_sync(const IgemmParams& p, hipStream_t s) {
+    static bool done = false;
+    return launch_kernel(igemm_kernel<T, BM, BN, WM, WN>, done, 2 * (BM + BN) * Mma<T>::PITCH,
+                         8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_async(const IgemmParams& p, hipStream_t s) {
+    static bool done = false;
+    return launch_kernel(igemm_async_kernel<T, BM, BN, WM, WN, STAGES>, done, STAGES * (BM + BN) * 128,
+                         8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
+}
+
+template <typename T, int BM, int BN, int WM, int WN> static int launch_tile(const IgemmParams& p, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (!kEnvSync) {
+            // ring depth: with <= ~1 workgroup per CU all latency hiding comes from the ring (4 deep);
+            // with more resident workgroups a shallower ring leaves LDS for 2+ workgroups per CU
+            const int wgs = p.tiles_m * p.tiles_n * p.splitk;
+            int stages = kEnvStages ? kEnvStages : (wgs <= 320 ? 4 : 3);
+            if ((BM + BN) * 128 * stages > 160 * 1024) stages = 160 * 1024 / ((BM + BN) * 128);
+            switch (stages) {
+                case 2: return launch_async<T, BM, BN, WM, WN, 2>(p, s);
+                case 3: return launch_async<T, BM, BN, WM, WN, 3>(p, s);
+                default: return launch_async<T, BM, BN, WM, WN, 4>(p, s);
+            }
+        }
+    }
+    return launch_sync<T, BM, BN, WM, WN>(p, s);
 }
 
 template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStream_t s) {
@@ -348,7 +611,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Pick tile + split-K.  Target: >= ~2 workgroups per CU (256 CUs) without shredding K below 4 tiles.
 static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& tile, int& splitk, size_t ws_bytes) {
-    const int target = 512;
+    const int target = kEnvTarget ? kEnvTarget : 512;
     if (tile == 0) {
         double best = -1;
         for (int t = 1; t <= kNumTiles; ++t) {
@@ -413,6 +676,26 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.splitk = cdiv(p.k_tiles, p.k_tiles_per_split);  // drop empty splits
     p.tiles_m = cdiv(p.M, kTiles[tile].bm);
     p.tiles_n = cdiv(d.n_pad, kTiles[tile].bn);
+    p.korder = d.k_order;
+    if (d.k_order)
+        MVLDM_REQUIRE(d.k_order == 1 && p.ctot % bk == 0 && d.c0 % bk == 0 && d.k_pad == p.taps * p.ctot,
+                      "igemm: k_order 1 needs channel counts (%d,%d) multiples of %d", d.c0, d.c1, bk);
+    // XCD grid px x py (px * py = 8): fabric traffic ~ py * bytes(A) + px * bytes(W), idle tiles penalised
+    {
+        const double a_bytes = (double)d.n_img * d.h_in * d.w_in * p.ctot, w_bytes = (double)d.n_pad * d.k_pad;
+        double best = 1e300;
+        for (int px = 1; px <= 8; px *= 2) {
+            const int py = 8 / px;
+            const int sm = cdiv(p.tiles_m, px), sn = cdiv(p.tiles_n, py);
+            const double waste = (double)(8 * sm * sn) / ((double)p.tiles_m * p.tiles_n);
+            const double cost = (py * a_bytes + px * w_bytes) * waste * waste;
+            if (cost < best) { best = cost; p.px = px; p.sub_m = sm; p.sub_n = sn; }
+        }
+        p.m_fast = w_bytes >= a_bytes;
+        if (kEnvPx > 0 && kEnvPx <= 8 && (8 % kEnvPx) == 0) {
+            p.px = kEnvPx; p.sub_m = cdiv(p.tiles_m, p.px); p.sub_n = cdiv(p.tiles_n, 8 / p.px);
+        }
+    }
     return MVLDM_OK;
 }
 
@@ -454,7 +737,9 @@ extern "C" size_t mvldm_igemm_workspace_bytes(const mvldm_igemm_desc* d) {
 }
 
 extern "C" int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksize, int c_pad, int n_pad,
-                                 int k_pad, int geglu, int dst_dtype, mvldm_stream_t stream) {
+                                 int k_pad, int geglu, int k_order, int dst_dtype, mvldm_stream_t stream) {
+    const int bk = dst_dtype == MVLDM_F32 ? 32 : 64;
+    MVLDM_REQUIRE(k_order == 0 || (k_order == 1 && c_pad % bk == 0), "pack_weight: k_order 1 needs c_pad %% %d == 0", bk);
     MVLDM_REQUIRE(src && dst && c_pad >= c_in && n_pad >= n_out && k_pad >= ksize * ksize * c_pad, "pack_weight: bad dims");
     MVLDM_REQUIRE(!geglu || n_out % 64 == 0, "pack_weight: GEGLU needs n_out %% 64 == 0");
     const size_t total = (size_t)n_pad * k_pad;
@@ -462,7 +747,7 @@ extern "C" int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_i
     return dispatch_dtype(dst_dtype, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
-                           reinterpret_cast<T*>(dst), n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu);
+                           reinterpret_cast<T*>(dst), n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu, k_order, bk);
         return check_launch();
     });
 }

@@ -67,14 +67,16 @@ def eager_builder(t: torch.Tensor) -> Builder:
 
 # ------------------------------------------------------------------------------------------ leaves
 class Conv2d(nn.Conv2d, _PackMixin):
-    def packed(self, dtype, c_pad=None) -> PackedWeight:
+    def packed(self, dtype, c_pad=None, c_split=None) -> PackedWeight:
         require_gpu(self.weight)
-        return self._cache(("w", dtype, c_pad), [self.weight], lambda: ops.pack_weight(self.weight, dtype, c_pad=c_pad))
+        aligned = c_split is None or c_split % ops.block_k(dtype) == 0
+        return self._cache(("w", dtype, c_pad, aligned), [self.weight],
+                           lambda: ops.pack_weight(self.weight, dtype, c_pad=c_pad, c_split=c_split))
 
     def emit(self, b: Builder, x, x2=None, **kw):
         c_tot = x.shape[-1] + (0 if x2 is None else x2.shape[-1])
-        return b.conv(x, self.packed(b.dtype, c_tot), self._f32("bias"), x2=x2, stride=self.stride[0],
-                      pad=self.padding[0], **kw)
+        return b.conv(x, self.packed(b.dtype, c_tot, None if x2 is None else x.shape[-1]), self._f32("bias"), x2=x2,
+                      stride=self.stride[0], pad=self.padding[0], **kw)
 
     def forward(self, x):
         b = eager_builder(x)

@@ -64,23 +64,31 @@ class PackedWeight:
     c_pad: int      # channels per tap as seen by the kernel (sum of source channels)
     ksize: int
     geglu: bool = False
+    k_order: int = 0    # 1: K stored as (channel block, tap, channel) -- needs every source's channels % BK == 0
 
 
-def pack_weight(w: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None, geglu: bool = False) -> PackedWeight:
-    """w: fp32 `[n_out, c_in, k, k]` (conv) or `[n_out, c_in]` (linear), on the GPU."""
+def block_k(dtype: torch.dtype) -> int:
+    return 32 if dtype == torch.float32 else 64
+
+
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None, geglu: bool = False,
+                c_split: Optional[int] = None) -> PackedWeight:
+    """w: fp32 `[n_out, c_in, k, k]` (conv) or `[n_out, c_in]` (linear), on the GPU.  `c_split`: channel
+    count of the first of two concatenated sources (decides whether the block-major K order applies)."""
     assert w.is_cuda, "pack_weight needs a device tensor (no CPU path)"
     w = w.detach().to(torch.float32).contiguous()
     n_out, c_in = w.shape[0], w.shape[1]
     ksize = w.shape[2] if w.ndim == 4 else 1
     e = epc(dtype)
     c_pad = _roundup(c_in, e) if c_pad is None else c_pad
-    bk = 32 if dtype == torch.float32 else 64
+    bk = block_k(dtype)
     k_pad = _roundup(ksize * ksize * c_pad, bk)
     n_pad = _roundup(n_out, 64)
+    k_order = int(c_pad % bk == 0 and (c_split is None or c_split % bk == 0))
     out = torch.empty(n_pad, k_pad, dtype=dtype, device=w.device)
     L.check(L.load().mvldm_pack_weight(w.data_ptr(), out.data_ptr(), n_out, c_in, ksize, c_pad, n_pad, k_pad,
-                                       int(geglu), dt(dtype), stream()))
-    return PackedWeight(out, n_out, n_pad, k_pad, c_pad, ksize, geglu)
+                                       int(geglu), k_order, dt(dtype), stream()))
+    return PackedWeight(out, n_out, n_pad, k_pad, c_pad, ksize, geglu, k_order)
 
 
 # ------------------------------------------------------------------------------------------ igemm
@@ -102,6 +110,8 @@ def igemm_desc(src0, src1, pw: PackedWeight, dst, *, n_img, h_in, w_in, h_out, w
     d.epilogue, d.act_dtype, d.dst_dtype = epilogue, dt(src0), dt(dst)
     d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
     d.dst_ld = 0
+    d.k_order = pw.k_order
+    assert not pw.k_order or c0 % block_k(src0.dtype) == 0, "weight packed block-major but the source split is unaligned"
     if ws is not None:
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     else:

@@ -131,6 +131,8 @@ class Builder:
         d.epilogue, d.act_dtype, d.dst_dtype = epilogue, dt(x), dt(out)
         d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
         d.dst_ld = out.shape[-1] if out.shape[-1] != n_dst else 0
+        d.k_order = pw.k_order
+        assert not pw.k_order or c0 % (32 if x.dtype == torch.float32 else 64) == 0, f"{name}: block-major weight, unaligned source split"
         if ws is not None:
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         else:

@@ -62,6 +62,9 @@ CONV_CASES = [
     ("3x3", 2, 64, 0, 96, 8, 8, 3, 1, 1, False),
     ("3x3_wide_odd", 3, 40, 0, 72, 5, 7, 3, 1, 1, False),
     ("3x3_concat", 2, 64, 32, 64, 8, 8, 3, 1, 1, False),
+    ("3x3_concat_aligned", 2, 128, 64, 96, 8, 8, 3, 1, 1, False),
+    ("3x3_upsample_wide", 1, 128, 0, 128, 8, 8, 3, 1, 1, True),
+    ("3x3_stride2_wide", 2, 128, 0, 64, 16, 16, 3, 2, 1, False),
     ("3x3_stride2", 2, 64, 0, 64, 8, 8, 3, 2, 1, False),
     ("3x3_stride2_asym_vae", 1, 32, 0, 32, 8, 8, 3, 2, 0, False),
     ("3x3_upsample", 2, 64, 0, 64, 4, 4, 3, 1, 1, True),
@@ -89,7 +92,7 @@ def test_conv_variants(ops, case, dtype):
     if k == 3 and stride == 2 and pad == 0:
         xr = F.pad(xr, (0, 1, 0, 1))
     ref = F.conv2d(xr, wt.double(), b.double(), stride=stride, padding=pad)
-    pw = ops.pack_weight(wt.cuda(), dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype, c_split=cin if cin2 else None)
     y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=None if x2 is None else nhwc(x2, dtype), stride=stride, pad=pad, upsample=up)
     close(nchw(y), ref, dtype, name)
 
@@ -177,9 +180,17 @@ def test_geglu(ops, dtype, rows, c):
 def test_pack_weight_layout(ops):
     w = torch.randn(70, 24, 3, 3, generator=G(24))
     pw = ops.pack_weight(w.cuda(), torch.float32)
+    assert pw.k_order == 0                      # 24 channels: tap-major K order
     ref = torch.zeros(pw.n_pad, pw.k_pad)
     ref[:70, :9 * 24] = w.permute(0, 2, 3, 1).reshape(70, -1)
     assert torch.equal(pw.data.cpu(), ref)
+    w2 = torch.randn(8, 128, 3, 3, generator=G(26))
+    p2 = ops.pack_weight(w2.cuda(), torch.bfloat16)
+    assert p2.k_order == 1                      # 128 channels: (64-channel block, tap, channel) K order
+    ref2 = torch.zeros(p2.n_pad, 2, 9, 64)
+    ref2[:8] = w2.reshape(8, 2, 64, 9).permute(0, 1, 3, 2)
+    assert torch.equal(p2.data.float().cpu(), ref2.reshape(p2.n_pad, -1).to(torch.bfloat16).float())
+    assert ops.pack_weight(w2.cuda(), torch.bfloat16, c_split=40).k_order == 0   # unaligned concat split
     wl = torch.randn(128, 16, generator=G(25))
     pg = ops.pack_weight(wl.cuda(), torch.float32, geglu=True).data.cpu()
     assert torch.equal(pg[0:32, :16], wl[0:32]) and torch.equal(pg[32:64, :16], wl[64:96])

@@ -12,7 +12,7 @@ from mv_ldm_amd import modules, mvunet, ops, pipeline, plan, runtime, vae
 
 @pytest.fixture()
 def cpu_record(monkeypatch):
-    def fake_pack(w, dtype, c_pad=None, geglu=False):
+    def fake_pack(w, dtype, c_pad=None, geglu=False, c_split=None):
         n_out, c_in = w.shape[0], w.shape[1]
         k = w.shape[2] if w.ndim == 4 else 1
         e = ops.epc(dtype)
@@ -20,7 +20,8 @@ def cpu_record(monkeypatch):
         bk = 32 if dtype == torch.float32 else 64
         k_pad = (k * k * c_pad + bk - 1) // bk * bk
         n_pad = (n_out + 63) // 64 * 64
-        return ops.PackedWeight(torch.empty(0), n_out, n_pad, k_pad, c_pad, k, geglu)
+        k_order = int(c_pad % bk == 0 and (c_split is None or c_split % bk == 0))
+        return ops.PackedWeight(torch.empty(0), n_out, n_pad, k_pad, c_pad, k, geglu, k_order)
     monkeypatch.setattr(ops, "pack_weight", fake_pack)
     for mod in (modules, mvunet, runtime, vae):
         monkeypatch.setattr(mod, "require_gpu", lambda t: None, raising=False)
