@@ -578,13 +578,15 @@ static int launch_async(const IgemmParams& p, hipStream_t s) {
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
 
+// per-call tuning overrides ride in the upper bits of desc.tile: bits 4-7 ring depth, 8-11 px, bit 12 sync loop
+static thread_local int t_force_stages = 0, t_force_sync = 0;
+
 template <typename T, int BM, int BN, int WM, int WN> static int launch_tile(const IgemmParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        if (!kEnvSync) {
-            // ring depth: with <= ~1 workgroup per CU all latency hiding comes from the ring (4 deep);
-            // with more resident workgroups a shallower ring leaves LDS for 2+ workgroups per CU
-            const int wgs = p.tiles_m * p.tiles_n * p.splitk;
-            int stages = kEnvStages ? kEnvStages : (wgs <= 320 ? 4 : 3);
+        if (!kEnvSync && !t_force_sync) {
+            // ring depth 2 measured best at every shape of this network: occupancy (3 workgroups per CU)
+            // hides more latency than a deeper ring that costs a resident workgroup
+            int stages = t_force_stages ? t_force_stages : kEnvStages ? kEnvStages : 2;
             if ((BM + BN) * 128 * stages > 160 * 1024) stages = 160 * 1024 / ((BM + BN) * 128);
             switch (stages) {
                 case 2: return launch_async<T, BM, BN, WM, WN, 2>(p, s);
@@ -613,19 +615,13 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& tile, int& splitk, size_t ws_bytes) {
     const int target = kEnvTarget ? kEnvTarget : 512;
     if (tile == 0) {
-        double best = -1;
-        for (int t = 1; t <= kNumTiles; ++t) {
-            const int tm = cdiv(M, kTiles[t].bm), tn = cdiv(d.n_pad, kTiles[t].bn);
-            const double util = (double)M * d.n_pad / ((double)tm * kTiles[t].bm * tn * kTiles[t].bn);
-            const int wgs = tm * tn;
-            int sk = 1;
-            if (wgs < target) sk = std::min(std::max(k_tiles / 4, 1), cdiv(target, wgs));
-            const double fill = std::min(1.0, (double)wgs * sk / target);
-            // bigger tiles reuse operands better: mild preference
-            const double reuse = 1.0 - 8.0 / (kTiles[t].bm + kTiles[t].bn) * 4.0;
-            const double score = util * (0.35 + 0.65 * fill) * (0.6 + 0.4 * reuse) * (sk > 1 ? 0.92 : 1.0);
-            if (score > best) { best = score; tile = t; }
-        }
+        // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep_*.json): the 32x64 wave tile
+        // wins everywhere at these sizes (3 workgroups per CU with a 2-deep ring); 128x64 for 3x3 convs
+        // and narrow N, 64x128 for wide Linear layers; tiny M gets the small tiles.
+        if (M <= 32) tile = 5;
+        else if (M <= 64) tile = 4;
+        else if (d.ksize == 3 || d.n_pad < 640) tile = 2;
+        else tile = 3;
     }
     const int tm = cdiv(M, kTiles[tile].bm), tn = cdiv(d.n_pad, kTiles[tile].bn);
     if (splitk == 0) {
@@ -664,7 +660,10 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
     MVLDM_REQUIRE(p.dst_ld >= p.n_dst, "igemm: dst_ld %d < n_dst %d", p.dst_ld, p.n_dst);
     p.k_tiles = d.k_pad / bk;
-    tile = d.tile;
+    tile = d.tile & 15;
+    t_force_stages = (d.tile >> 4) & 15;
+    t_force_sync = (d.tile >> 12) & 1;
+    const int force_px = (d.tile >> 8) & 15;
     int splitk = d.splitk;
     MVLDM_REQUIRE(tile >= 0 && tile <= kNumTiles && splitk >= 0, "igemm: tile/splitk");
     choose_config(d, p.M, p.k_tiles, tile, splitk, d.workspace_bytes);
@@ -692,8 +691,9 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
             if (cost < best) { best = cost; p.px = px; p.sub_m = sm; p.sub_n = sn; }
         }
         p.m_fast = w_bytes >= a_bytes;
-        if (kEnvPx > 0 && kEnvPx <= 8 && (8 % kEnvPx) == 0) {
-            p.px = kEnvPx; p.sub_m = cdiv(p.tiles_m, p.px); p.sub_n = cdiv(p.tiles_n, 8 / p.px);
+        const int fpx = force_px ? force_px : kEnvPx;
+        if (fpx > 0 && fpx <= 8 && (8 % fpx) == 0) {
+            p.px = fpx; p.sub_m = cdiv(p.tiles_m, p.px); p.sub_n = cdiv(p.tiles_n, 8 / p.px);
         }
     }
     return MVLDM_OK;
