@@ -34,6 +34,8 @@ struct IgemmParams {
     int tiles_m, tiles_n;
     int korder;                 // 0: k = (tap, channel)   1: k = (channel block of BK, tap, channel in block)
     int px, sub_m, sub_n, m_fast;  // XCD-aware 2-D tile partition
+    unsigned src0_bytes, src1_bytes, w_bytes;   // buffer-descriptor extents (lean 16-bit loop)
+    int use_bl;
 };
 
 // ---- per-dtype MFMA + LDS policy -------------------------------------------------------------------
@@ -483,6 +485,155 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_async_kernel(const IgemmPar
     igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
 }
 
+// ---- 16-bit main loop, lean form: buffer-load LDS-DMA, unrolled taps -----------------------------------
+// For the block-major K order every K-tile is (64-channel block cb, tap): the tap loop is unrolled, so each
+// lane's pixel offset for each tap is a REGISTER computed once per workgroup (out-of-image taps and rows
+// beyond M hold an out-of-range offset: the buffer descriptor's bounds check returns zeros, which the DMA
+// writes to LDS -- no zero page, no select).  Inside the loop a tile costs per wave: A_IT + B_IT
+// `buffer_load_dwordx4 ... lds` with a scalar soffset (channel block / K position), the M0 updates, the
+// fragment ds_reads and the MFMAs -- no vector address arithmetic at all (PMC of the previous loop: 11
+// VALU + 16 SALU instructions per MFMA).
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams p) {
+    using M_ = Mma<T>;
+    static_assert(sizeof(T) == 2, "16-bit activation types only");
+    constexpr int NW = WM * WN, TAPS = KS * KS;
+    constexpr int BK = 64, EPC = 8;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
+    static_assert(A_IT >= 1 && B_IT >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "bad tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    int split, tm, tn;
+    if (!map_block(p, split, tm, tn)) return;
+    // split-K partitions channel blocks (k_tiles_per_split is a multiple of TAPS for this kernel)
+    const int cb0 = split * (p.k_tiles_per_split / TAPS);
+    const int cb1 = min(cb0 + p.k_tiles_per_split / TAPS, p.k_tiles / TAPS);
+
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DUAL ? p.src1 : p.src0), 0,
+                                                                         DUAL ? p.src1_bytes : p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+
+    const int slot = lane & 7, rsub = lane >> 3;
+    const unsigned hs = p.upsample ? 2 * p.h_in : p.h_in, wsz = p.upsample ? 2 * p.w_in : p.w_in;
+    const int ups = p.upsample ? 1 : 0;
+    unsigned va0[TAPS][A_IT], va1[DUAL ? TAPS : 1][DUAL ? A_IT : 1];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (wave + NW * it) * 8 + rsub;
+        const int m = tm * BM + row;
+        const unsigned chunk = (unsigned)((slot ^ ((row >> 1) & 7)) * EPC);
+        int pix0 = 0, y0 = -(1 << 20), x0 = 0;
+        if (m < p.M) {
+            const int img = m / p.hw_out, rem = m - img * p.hw_out;
+            const int oy = rem / p.w_out;
+            pix0 = img * p.h_in;
+            y0 = oy * p.stride - p.pad;
+            x0 = (rem - oy * p.w_out) * p.stride - p.pad;
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int iy = y0 + t / KS, ix = x0 + t % KS;
+            const bool ok = (unsigned)iy < hs && (unsigned)ix < wsz;
+            const unsigned pix = (unsigned)(pix0 + (iy >> ups)) * (unsigned)p.w_in + (unsigned)(ix >> ups);
+            va0[t][it] = ok ? (pix * (unsigned)p.c0 + chunk) * 2u : kOob;
+            if constexpr (DUAL) va1[t][it] = ok ? (pix * (unsigned)p.c1 + chunk) * 2u : kOob;
+        }
+    }
+    unsigned vb[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int row = (wave + NW * it) * 8 + rsub;
+        const int n = tn * BN + row;
+        const unsigned chunk = (unsigned)((slot ^ ((row >> 1) & 7)) * EPC);
+        vb[it] = n < p.n_pad ? ((unsigned)n * (unsigned)p.k_pad + chunk) * 2u : kOob;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // issue K-tile (cb, tap) into `stage`: tap is a compile-time constant at every call site
+    auto issue = [&](int stage, int cb, auto tap_c) {
+        constexpr int t = decltype(tap_c)::value;
+        char* at = smem + stage * STAGE_BYTES;
+        char* bt = at + A_BYTES;
+        const int c = cb * BK;
+        const bool from0 = !DUAL || c < p.c0;
+        const int soff = (from0 ? c : c - p.c0) * 2;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024);
+            if (from0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, va0[t][it], soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, va1[DUAL ? t : 0][DUAL ? it : 0], soff, 0, 0);
+        }
+        const int koff = (cb * TAPS + t) * (BK * 2);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(bt + (wave + NW * it) * 1024), 16,
+                                                     vb[it], koff, 0, 0);
+    };
+    auto compute = [&](int stage) {
+        const char* at = smem + stage * STAGE_BYTES;
+        const char* bt = at + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / M_::KI; ++kk) {
+            typename M_::Frag a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+        }
+    };
+    // one K-tile: my pieces landed + my reads of the other slot retired -> barrier -> prefetch next -> MFMAs
+    if (cb0 < cb1) {
+        issue(0, cb0, std::integral_constant<int, 0>{});
+        int par = 0;   // ring slot of the tile being consumed
+        for (int cb = cb0; cb < cb1; ++cb) {
+            // taps unrolled by hand through a constexpr-for
+            auto body = [&](auto tap_c) {
+                constexpr int t = decltype(tap_c)::value;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if constexpr (t + 1 < TAPS) {
+                    issue(par ^ 1, cb, std::integral_constant<int, t + 1>{});
+                } else {
+                    if (cb + 1 < cb1) issue(par ^ 1, cb + 1, std::integral_constant<int, 0>{});
+                }
+                compute(par);
+                par ^= 1;
+            };
+            if constexpr (TAPS == 1) {
+                body(std::integral_constant<int, 0>{});
+            } else {
+                body(std::integral_constant<int, 0>{}); body(std::integral_constant<int, 1>{});
+                body(std::integral_constant<int, 2>{}); body(std::integral_constant<int, 3>{});
+                body(std::integral_constant<int, 4>{}); body(std::integral_constant<int, 5>{});
+                body(std::integral_constant<int, 6>{}); body(std::integral_constant<int, 7>{});
+                body(std::integral_constant<int, 8>{});
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
+}
+
 // split-K: sum the fp32 partial slabs and run the same epilogue (deterministic, no atomics)
 template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmParams p) {
     const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
@@ -539,8 +690,9 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 
 // ---- host side ------------------------------------------------------------------------------------
 struct TileCfg { int bm, bn, threads; };
-static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64, 128, 256}, {64, 64, 128}, {32, 64, 64}};
-constexpr int kNumTiles = 5;
+static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64, 128, 256}, {64, 64, 128}, {32, 64, 64},
+                                 {256, 64, 256}};   // tile 6: 64x64 wave tile, lean 16-bit loop only
+constexpr int kNumTiles = 6;
 
 // tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
 // target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
@@ -552,6 +704,7 @@ static const int kEnvStages = env_int("MVLDM_IGEMM_STAGES", 0);
 static const int kEnvTarget = env_int("MVLDM_IGEMM_TARGET", 0);
 static const int kEnvSync = env_int("MVLDM_IGEMM_SYNC", 0);
 static const int kEnvPx = env_int("MVLDM_IGEMM_PX", 0);
+static const int kEnvAsync = env_int("MVLDM_IGEMM_ASYNC", 0);
 
 template <typename KernT> static int launch_kernel(KernT kern, bool& attr_done, int smem, int blocks, int threads,
                                                    const IgemmParams& p, hipStream_t s) {
@@ -578,11 +731,25 @@ static int launch_async(const IgemmParams& p, hipStream_t s) {
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
 
-// per-call tuning overrides ride in the upper bits of desc.tile: bits 4-7 ring depth, 8-11 px, bit 12 sync loop
-static thread_local int t_force_stages = 0, t_force_sync = 0;
+// per-call tuning overrides ride in the upper bits of desc.tile: bits 4-7 ring depth, 8-11 px, bit 12 sync loop,
+// bit 13 previous (zero-page) DMA loop
+static thread_local int t_force_stages = 0, t_force_sync = 0, t_force_async = 0;
+
+template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
+static int launch_bl(const IgemmParams& p, hipStream_t s) {
+    static bool done = false;
+    return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL>, done, 2 * (BM + BN) * 128,
+                         8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
+}
+template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(const IgemmParams& p, hipStream_t s) {
+    const bool dual = p.c1 > 0;
+    if (p.ksize == 3) return dual ? launch_bl<T, BM, BN, WM, WN, 3, true>(p, s) : launch_bl<T, BM, BN, WM, WN, 3, false>(p, s);
+    return dual ? launch_bl<T, BM, BN, WM, WN, 1, true>(p, s) : launch_bl<T, BM, BN, WM, WN, 1, false>(p, s);
+}
 
 template <typename T, int BM, int BN, int WM, int WN> static int launch_tile(const IgemmParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
+        if (p.use_bl) return launch_bl_any<T, BM, BN, WM, WN>(p, s);
         if (!kEnvSync && !t_force_sync) {
             // ring depth 2 measured best at every shape of this network: occupancy (3 workgroups per CU)
             // hides more latency than a deeper ring that costs a resident workgroup
@@ -605,6 +772,11 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
         case 3: return launch_tile<T, 64, 128, 2, 2>(p, s);
         case 4: return launch_tile<T, 64, 64, 2, 1>(p, s);
         case 5: return launch_tile<T, 32, 64, 1, 1>(p, s);
+        case 6:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_bl_any<T, 256, 64, 4, 1>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 6 needs the 16-bit block-major path");
         default: return set_error(MVLDM_ERR_ARG, "igemm: bad tile %d", tile);
     }
 }
@@ -663,6 +835,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     tile = d.tile & 15;
     t_force_stages = (d.tile >> 4) & 15;
     t_force_sync = (d.tile >> 12) & 1;
+    t_force_async = (d.tile >> 13) & 1;
     const int force_px = (d.tile >> 8) & 15;
     int splitk = d.splitk;
     MVLDM_REQUIRE(tile >= 0 && tile <= kNumTiles && splitk >= 0, "igemm: tile/splitk");
@@ -670,9 +843,24 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     if (splitk > 1)
         MVLDM_REQUIRE(d.workspace && (size_t)splitk * p.M * d.n_pad * sizeof(float) <= d.workspace_bytes,
                       "igemm: split-K workspace too small");
+    // lean 16-bit loop: block-major K, extents addressable by a 32-bit buffer offset
+    const double es = 2.0;
+    const double b0 = (double)d.n_img * d.h_in * d.w_in * d.c0 * es, b1 = (double)d.n_img * d.h_in * d.w_in * d.c1 * es;
+    const double bw = (double)d.n_pad * d.k_pad * es;
+    p.use_bl = d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !t_force_async && !kEnvSync && !kEnvAsync &&
+               b0 < 4.0e9 && b1 < 4.0e9 && bw < 4.0e9;
+    p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
+    if (tile == 6 && !p.use_bl) tile = 2;
     p.splitk = splitk;
-    p.k_tiles_per_split = cdiv(p.k_tiles, splitk);
-    p.splitk = cdiv(p.k_tiles, p.k_tiles_per_split);  // drop empty splits
+    if (p.use_bl) {   // splits own whole channel blocks (all taps of a block stay together)
+        const int cbs = p.k_tiles / p.taps;
+        const int per = cdiv(cbs, std::min(splitk, cbs));
+        p.k_tiles_per_split = per * p.taps;
+        p.splitk = cdiv(cbs, per);
+    } else {
+        p.k_tiles_per_split = cdiv(p.k_tiles, splitk);
+        p.splitk = cdiv(p.k_tiles, p.k_tiles_per_split);  // drop empty splits
+    }
     p.tiles_m = cdiv(p.M, kTiles[tile].bm);
     p.tiles_n = cdiv(d.n_pad, kTiles[tile].bn);
     p.korder = d.k_order;

@@ -106,10 +106,14 @@ def test_conv_tiles_and_splitk(ops, dtype):
     ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
     pw = ops.pack_weight(wt.cuda(), dtype)
     xg = nhwc(x, dtype)
-    for tile in (1, 2, 3, 4, 5):
+    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6)
+    for tile in tiles:
         for sk in (1, 2, 5):
             y = ops.conv2d(xg, pw, b.cuda(), tile=tile, splitk=sk)
             close(nchw(y), ref, dtype, f"tile{tile}/splitk{sk}")
+    if dtype != torch.float32:   # the other two 16-bit main loops (bit 12: register prefetch, bit 13: zero-page DMA ring)
+        for code in (2 | (1 << 12), 2 | (1 << 13) | (3 << 4), 3 | (1 << 13) | (2 << 4)):
+            close(nchw(ops.conv2d(xg, pw, b.cuda(), tile=code, splitk=2)), ref, dtype, f"tilecode {code:#x}")
     close(nchw(ops.conv2d(xg, pw, b.cuda())), ref, dtype, "auto")
 
 
