@@ -495,6 +495,56 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_async_kernel(const IgemmPar
 // VALU + 16 SALU instructions per MFMA).
 constexpr unsigned kOob = 0xFFFFFFF0u;
 
+// issue K-tile (channel block cb, tap t) into the ring slot at `stage_base`
+template <typename T, int BM, int BN, int NW, int TAPS, bool DUAL, int A_IT, int B_IT, int t>
+__device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base, int wave, int cb,
+                                         const unsigned (&va0)[TAPS][A_IT], const unsigned (&va1)[DUAL ? TAPS : 1][DUAL ? A_IT : 1],
+                                         const unsigned (&vb)[B_IT]) {
+    constexpr int BK = 64;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DUAL ? p.src1 : p.src0), 0,
+                                                                         DUAL ? p.src1_bytes : p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+    char* at = stage_base;
+    char* bt = at + BM * 128;
+    const int c = cb * BK;
+    const bool from0 = !DUAL || c < p.c0;
+    const int soff = (from0 ? c : c - p.c0) * 2;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024);
+        if (from0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, va0[t][it], soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, va1[DUAL ? t : 0][DUAL ? it : 0], soff, 0, 0);
+    }
+    const int koff = (cb * TAPS + t) * (BK * 2);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(bt + (wave + NW * it) * 1024), 16,
+                                                 vb[it], koff, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void bl_compute(const char* stage_base, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn,
+                                           int hi, int l31) {
+    using M_ = Mma<T>;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const char* at = stage_base;
+    const char* bt = at + BM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 64 / M_::KI; ++kk) {
+        typename M_::Frag a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
+    }
+}
+
+
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams p) {
     using M_ = Mma<T>;
@@ -516,11 +566,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     // split-K partitions channel blocks (k_tiles_per_split is a multiple of TAPS for this kernel)
     const int cb0 = split * (p.k_tiles_per_split / TAPS);
     const int cb1 = min(cb0 + p.k_tiles_per_split / TAPS, p.k_tiles / TAPS);
-
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.src0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DUAL ? p.src1 : p.src0), 0,
-                                                                         DUAL ? p.src1_bytes : p.src0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
 
     const int slot = lane & 7, rsub = lane >> 3;
     const unsigned hs = p.upsample ? 2 * p.h_in : p.h_in, wsz = p.upsample ? 2 * p.w_in : p.w_in;
@@ -565,71 +610,32 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // issue K-tile (cb, tap) into `stage`: tap is a compile-time constant at every call site
-    auto issue = [&](int stage, int cb, auto tap_c) {
-        constexpr int t = decltype(tap_c)::value;
-        char* at = smem + stage * STAGE_BYTES;
-        char* bt = at + A_BYTES;
-        const int c = cb * BK;
-        const bool from0 = !DUAL || c < p.c0;
-        const int soff = (from0 ? c : c - p.c0) * 2;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024);
-            if (from0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, va0[t][it], soff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, va1[DUAL ? t : 0][DUAL ? it : 0], soff, 0, 0);
-        }
-        const int koff = (cb * TAPS + t) * (BK * 2);
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(bt + (wave + NW * it) * 1024), 16,
-                                                     vb[it], koff, 0, 0);
-    };
-    auto compute = [&](int stage) {
-        const char* at = smem + stage * STAGE_BYTES;
-        const char* bt = at + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < BK / M_::KI; ++kk) {
-            typename M_::Frag a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
-        }
-    };
-    // one K-tile: my pieces landed + my reads of the other slot retired -> barrier -> prefetch next -> MFMAs
+    // (no lambdas around the buffer builtins: an opaque __amdgpu_buffer_rsrc_t inside a lambda makes the
+    //  host pass drop the kernel's stub -- free function templates instead)
+#define MVLDM_BL_ISSUE(stage_, cb_, t_) \
+    bl_issue<T, BM, BN, NW, TAPS, DUAL, A_IT, B_IT, t_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, va0, va1, vb)
+#define MVLDM_BL_STEP(t_)                                                                     \
+    {                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
+        __builtin_amdgcn_s_barrier();                                                         \
+        if constexpr ((t_) + 1 < TAPS) { MVLDM_BL_ISSUE(par ^ 1, cb, ((t_) + 1 < TAPS ? (t_) + 1 : 0)); } \
+        else { if (cb + 1 < cb1) MVLDM_BL_ISSUE(par ^ 1, cb + 1, 0); }                       \
+        bl_compute<T, BM, BN, WM, WN>(smem + par * STAGE_BYTES, acc, wm, wn, hi, l31);       \
+        par ^= 1;                                                                             \
+    }
     if (cb0 < cb1) {
-        issue(0, cb0, std::integral_constant<int, 0>{});
+        MVLDM_BL_ISSUE(0, cb0, 0);
         int par = 0;   // ring slot of the tile being consumed
         for (int cb = cb0; cb < cb1; ++cb) {
-            // taps unrolled by hand through a constexpr-for
-            auto body = [&](auto tap_c) {
-                constexpr int t = decltype(tap_c)::value;
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if constexpr (t + 1 < TAPS) {
-                    issue(par ^ 1, cb, std::integral_constant<int, t + 1>{});
-                } else {
-                    if (cb + 1 < cb1) issue(par ^ 1, cb + 1, std::integral_constant<int, 0>{});
-                }
-                compute(par);
-                par ^= 1;
-            };
-            if constexpr (TAPS == 1) {
-                body(std::integral_constant<int, 0>{});
-            } else {
-                body(std::integral_constant<int, 0>{}); body(std::integral_constant<int, 1>{});
-                body(std::integral_constant<int, 2>{}); body(std::integral_constant<int, 3>{});
-                body(std::integral_constant<int, 4>{}); body(std::integral_constant<int, 5>{});
-                body(std::integral_constant<int, 6>{}); body(std::integral_constant<int, 7>{});
-                body(std::integral_constant<int, 8>{});
+            MVLDM_BL_STEP(0)
+            if constexpr (TAPS == 9) {
+                MVLDM_BL_STEP(1) MVLDM_BL_STEP(2) MVLDM_BL_STEP(3) MVLDM_BL_STEP(4)
+                MVLDM_BL_STEP(5) MVLDM_BL_STEP(6) MVLDM_BL_STEP(7) MVLDM_BL_STEP(8)
             }
         }
     }
+#undef MVLDM_BL_STEP
+#undef MVLDM_BL_ISSUE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
 }
