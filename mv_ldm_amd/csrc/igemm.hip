@@ -496,7 +496,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_async_kernel(const IgemmPar
 constexpr unsigned kOob = 0xFFFFFFF0u;
 
 // issue K-tile (channel block cb, tap t) into the ring slot at `stage_base`
-template <typename T, int BM, int BN, int NW, int TAPS, bool DUAL, int A_IT, int B_IT, int t>
+// (STAGES is carried only to give every kernel instantiation its own copy: sharing one specialization
+//  between two kernels trips the host pass of hipcc 7.2)
+template <typename T, int BM, int BN, int NW, int TAPS, bool DUAL, int A_IT, int B_IT, int STAGES, int t>
 __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base, int wave, int cb,
                                          const unsigned (&va0)[TAPS][A_IT], const unsigned (&va1)[DUAL ? TAPS : 1][DUAL ? A_IT : 1],
                                          const unsigned (&vb)[B_IT]) {
@@ -523,6 +525,15 @@ __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base,
                                                  vb[it], koff, 0, 0);
 }
 
+template <int BM, int NW, int LPT>
+__device__ __forceinline__ void bl_issue_dummy(const IgemmParams& p, char* stage_base, int wave) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < LPT; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(stage_base + (wave + NW * it) * 1024), 16,
+                                                 kOob, 0, 0, 0);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void bl_compute(const char* stage_base, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn,
                                            int hi, int l31) {
@@ -545,7 +556,7 @@ __device__ __forceinline__ void bl_compute(const char* stage_base, f32x16 (&acc)
 }
 
 
-template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
+template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams p) {
     using M_ = Mma<T>;
     static_assert(sizeof(T) == 2, "16-bit activation types only");
@@ -553,8 +564,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     constexpr int BK = 64, EPC = 8;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, LPT = A_IT + B_IT;
     static_assert(A_IT >= 1 && B_IT >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "bad tile");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -613,19 +625,36 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     // (no lambdas around the buffer builtins: an opaque __amdgpu_buffer_rsrc_t inside a lambda makes the
     //  host pass drop the kernel's stub -- free function templates instead)
 #define MVLDM_BL_ISSUE(stage_, cb_, t_) \
-    bl_issue<T, BM, BN, NW, TAPS, DUAL, A_IT, B_IT, t_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, va0, va1, vb)
-#define MVLDM_BL_STEP(t_)                                                                     \
-    {                                                                                         \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
-        __builtin_amdgcn_s_barrier();                                                         \
-        if constexpr ((t_) + 1 < TAPS) { MVLDM_BL_ISSUE(par ^ 1, cb, ((t_) + 1 < TAPS ? (t_) + 1 : 0)); } \
-        else { if (cb + 1 < cb1) MVLDM_BL_ISSUE(par ^ 1, cb + 1, 0); }                       \
-        bl_compute<T, BM, BN, WM, WN>(smem + par * STAGE_BYTES, acc, wm, wn, hi, l31);       \
-        par ^= 1;                                                                             \
+    bl_issue<T, BM, BN, NW, TAPS, DUAL, A_IT, B_IT, STAGES, t_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, va0, va1, vb)
+    // past the end of K: keep the per-wave piece count uniform (counted vmcnt) with out-of-range (zero) pieces
+#define MVLDM_BL_DUMMY(stage_) bl_issue_dummy<BM, NW, A_IT + B_IT>(p, smem + (stage_) * STAGE_BYTES, wave)
+#define MVLDM_BL_NEXT(t_, d_) (((t_) + (d_)) % TAPS)
+#define MVLDM_BL_STEP(t_)                                                                                         \
+    {                                                                                                             \
+        /* my pieces of this tile landed (STAGES-2 newer tiles may still fly); my reads of the slot about to */  \
+        /* be refilled retired */                                                                                 \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * LPT) : "memory");                      \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        {                                                                                                         \
+            /* (no constexpr locals as template arguments: the host pass rejects them inside a kernel) */       \
+            const int cbn_ = cb + ((t_) + STAGES - 1) / TAPS;                                                     \
+            if (cbn_ < cb1) { MVLDM_BL_ISSUE(slot_l, cbn_, MVLDM_BL_NEXT(t_, STAGES - 1)); }                      \
+            else { MVLDM_BL_DUMMY(slot_l); }                                                                      \
+        }                                                                                                         \
+        bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
+        slot_c = slot_c + 1 == STAGES ? 0 : slot_c + 1;                                                           \
+        slot_l = slot_l + 1 == STAGES ? 0 : slot_l + 1;                                                           \
     }
     if (cb0 < cb1) {
-        MVLDM_BL_ISSUE(0, cb0, 0);
-        int par = 0;   // ring slot of the tile being consumed
+        // prologue: STAGES-1 tiles in flight
+        {
+            MVLDM_BL_ISSUE(0, cb0, 0);
+            if constexpr (STAGES == 3) {
+                const int cbn_ = cb0 + 1 / TAPS;
+                if (cbn_ < cb1) { MVLDM_BL_ISSUE(1, cbn_, (1 % TAPS)); } else { MVLDM_BL_DUMMY(1); }
+            }
+        }
+        int slot_c = 0, slot_l = STAGES - 1;
         for (int cb = cb0; cb < cb1; ++cb) {
             MVLDM_BL_STEP(0)
             if constexpr (TAPS == 9) {
@@ -634,6 +663,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
             }
         }
     }
+#undef MVLDM_BL_NEXT
+#undef MVLDM_BL_DUMMY
 #undef MVLDM_BL_STEP
 #undef MVLDM_BL_ISSUE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -741,11 +772,17 @@ static int launch_async(const IgemmParams& p, hipStream_t s) {
 // bit 13 previous (zero-page) DMA loop
 static thread_local int t_force_stages = 0, t_force_sync = 0, t_force_async = 0;
 
+template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES>
+static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
+    static bool done = false;
+    return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES>, done, STAGES * (BM + BN) * 128,
+                         8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
+}
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
 static int launch_bl(const IgemmParams& p, hipStream_t s) {
-    static bool done = false;
-    return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL>, done, 2 * (BM + BN) * 128,
-                         8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
+    const int stages = t_force_stages ? t_force_stages : (kEnvStages ? kEnvStages : 2);
+    if (stages >= 3 && 3 * (BM + BN) * 128 <= 160 * 1024) return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, 3>(p, s);
+    return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, 2>(p, s);
 }
 template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(const IgemmParams& p, hipStream_t s) {
     const bool dual = p.c1 > 0;

@@ -47,8 +47,9 @@ for name, ni, h, c0, c1, co, k, geglu in SHAPES:
     best = None
     combos = []
     for tile in (1, 2, 3, 4, 6):
-        for sk in (1, 0):
-            combos.append((tile, 0, sk, 0, 0))       # lean buffer-load loop (default for block-major K)
+        for st in (2, 3):
+            for sk in (1, 0):
+                combos.append((tile, st, sk, 0, 0))   # lean buffer-load loop (default for block-major K), ring depth st
     for tile in (2, 3):
         combos.append((tile, 2, 0, 0, 2))            # previous zero-page DMA loop (bit 13)
         combos.append((tile, 0, 1, 0, 1))            # register-prefetch loop (bit 12)
