@@ -35,7 +35,7 @@ struct IgemmParams {
     int korder;                 // 0: k = (tap, channel)   1: k = (channel block of BK, tap, channel in block)
     int px, sub_m, sub_n, m_fast;  // XCD-aware 2-D tile partition
     unsigned src0_bytes, src1_bytes, w_bytes;   // buffer-descriptor extents (lean 16-bit loop)
-    int use_bl;
+    int use_bl, stage_epi;
 };
 
 // ---- per-dtype MFMA + LDS policy -------------------------------------------------------------------
@@ -171,6 +171,99 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
                     epilogue_store<T>(p, m, n, v);
                 }
+            }
+        }
+    }
+}
+
+// ---- LDS-staged epilogue (16-bit loops) --------------------------------------------------------------
+// The MFMA accumulator layout gives a lane ONE column and 16 scattered rows: storing from it means 2-byte
+// stores in 64-byte runs (and the residual is read the same way).  Here every wave parks a finished
+// 32-row block of its tile in LDS as fp32 (bias / time-embedding row / SiLU / GEGLU / scale already
+// applied, nothing rounded yet), then re-reads it row-major: each lane owns 8 consecutive output
+// columns -> one 16-byte residual load, one rounding, one 16-byte store; a store instruction covers 8
+// full 128-byte lines.  Split-K partial slabs take the same route with 16-byte fp32 stores.
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tm,
+                                                      int tn, int split, int wm, int wn, int wave, int lane, char* smem) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int WCOLS = BN / WN;          // packed columns of a wave tile
+    constexpr int PITCH = WCOLS + 4;        // floats
+    const int hi = lane >> 5, l31 = lane & 31;
+    const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
+    const bool partial = p.splitk > 1;
+    float* st = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
+    const int ncol0_packed = tn * BN + wn * WCOLS;                       // first packed column of this wave
+    const int wc = (geglu && !partial) ? WCOLS / 2 : WCOLS;              // output columns held by this wave
+    const int ncol0 = (geglu && !partial) ? (ncol0_packed >> 1) : ncol0_packed;
+    const int n_lim = partial ? p.n_pad : p.n_dst;
+    __syncthreads();   // every wave is done with the operand ring
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // ---- park: finished values, fp32, [row][col] ----
+        if (partial) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + j * 32 + l31] = acc[i][j][r];
+        } else if (geglu) {
+            if constexpr (TN % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int col = ncol0 + (j >> 1) * 32 + l31;
+                    const float bv = (p.bias && col < p.n_dst) ? p.bias[col] : 0.f;
+                    const float bg = (p.bias && col < p.n_dst) ? p.bias[p.n_dst + col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + (j >> 1) * 32 + l31] =
+                            (acc[i][j][r] + bv) * gelu_erf_f(acc[i][j + 1][r] + bg) * p.out_scale;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = ncol0 + j * 32 + l31;
+                const float bv = (p.bias && n < p.n_out) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = acc[i][j][r] + bv;
+                    if (p.row_bias) {
+                        const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
+                        if (m < p.M && n < p.n_out) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
+                    }
+                    if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
+                    st[row * PITCH + j * 32 + l31] = v * p.out_scale;
+                }
+            }
+        }
+        // (same wave wrote and reads: LDS serves a wave's requests in order; the compiler's own lgkmcnt
+        //  wait covers the data dependence through `st`)
+        // ---- re-read row-major, 8 columns per lane ----
+        const int cpr = wc >> 3;                  // 8-column chunks per row
+        const int total = 32 * cpr;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int row = idx / cpr, ch = idx - row * cpr;
+            const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
+            const int n0 = ncol0 + ch * 8;
+            if (m >= p.M || n0 >= n_lim) continue;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8 + 4);
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            if (partial) {
+                float* o = p.ws + (size_t)split * p.M * p.n_pad + (size_t)m * p.n_pad + n0;
+                *reinterpret_cast<f32x4*>(o) = a;
+                *reinterpret_cast<f32x4*>(o + 4) = b;
+            } else {
+                if (p.residual) {
+                    const Chunk<T> rc = load_chunk<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.n_dst + n0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rc.get(e);
+                }
+                Chunk<T> oc;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) oc.set(e, v[e]);
+                store_chunk<T>(reinterpret_cast<T*>(p.dst) + (size_t)m * p.dst_ld + n0, oc);
             }
         }
     }
@@ -668,7 +761,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
 #undef MVLDM_BL_STEP
 #undef MVLDM_BL_ISSUE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
+    if (p.stage_epi) igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
+    else igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
 }
 
 // split-K: sum the fp32 partial slabs and run the same epilogue (deterministic, no atomics)
@@ -742,6 +836,7 @@ static const int kEnvTarget = env_int("MVLDM_IGEMM_TARGET", 0);
 static const int kEnvSync = env_int("MVLDM_IGEMM_SYNC", 0);
 static const int kEnvPx = env_int("MVLDM_IGEMM_PX", 0);
 static const int kEnvAsync = env_int("MVLDM_IGEMM_ASYNC", 0);
+static const int kEnvNoStage = env_int("MVLDM_IGEMM_NOSTAGE", 0);
 
 template <typename KernT> static int launch_kernel(KernT kern, bool& attr_done, int smem, int blocks, int threads,
                                                    const IgemmParams& p, hipStream_t s) {
@@ -904,6 +999,8 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
         p.k_tiles_per_split = cdiv(p.k_tiles, splitk);
         p.splitk = cdiv(p.k_tiles, p.k_tiles_per_split);  // drop empty splits
     }
+    // LDS-staged epilogue: 16-byte rows need 8-column alignment of the 16-bit output (or a split-K slab)
+    p.stage_epi = p.use_bl && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
     p.tiles_m = cdiv(p.M, kTiles[tile].bm);
     p.tiles_n = cdiv(d.n_pad, kTiles[tile].bn);
     p.korder = d.k_order;
