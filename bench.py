@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scenes", type=int, default=int(os.environ.get("MVLDM_BENCH_SCENES", "4")))
+    ap.add_argument("--scenes", type=int, default=int(os.environ.get("MVLDM_BENCH_SCENES", "16")))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--res", type=int, default=256)
@@ -172,10 +172,8 @@ def main():
         img, _ = pipe.sample(batch)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from mv_ldm_amd.dist import max_over_ranks
+    elapsed = max_over_ranks(elapsed, dev)      # the only cross-rank exchange: no data-path collective
     assert torch.isfinite(img).all()
     views = world * b * v_t * args.steps
     value = views / elapsed

@@ -1,0 +1,67 @@
+"""CPU: host-side logic of the product path that needs no GPU -- camera / ray geometry vs the reference's
+own outputs (G3), the scheduler's integer and fp32 tables vs G6 (bit-exact) -- and the "fail loudly" rule."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+
+def test_rays_and_relative_poses_vs_reference(golden):
+    from mv_ldm_amd.pipeline import absolute_to_relative_camera, get_world_rays, ray_encode, sample_image_grid
+    g = golden("g3_rays")
+    extr, intr = torch.from_numpy(g["extrinsics"]), torch.from_numpy(g["intrinsics"])
+    for (h, w) in [(8, 8), (4, 6)]:
+        xy, ij = sample_image_grid((h, w))
+        assert torch.equal(xy, torch.from_numpy(g[f"xy_{h}x{w}"]))
+        assert ij.shape == (h, w, 2) and ij[1, 2].tolist() == [1, 2]
+        o, d = get_world_rays(xy.reshape(h * w, 2), extr[:, :, None], intr[:, :, None])
+        assert rel_err(o, g[f"origins_{h}x{w}"]) < 1e-7 and rel_err(d, g[f"directions_{h}x{w}"]) < 1e-6
+    enc = ray_encode(extr[:, :1], intr[:, :1], extr[:, 1:], intr[:, 1:], 8, 8)
+    assert enc.shape == (2, 4, 6, 8, 8)
+    assert rel_err(enc[:, :, 3:].permute(0, 1, 3, 4, 2).reshape(2, 4, 64, 3), g["directions_8x8"]) < 1e-6
+    for idx in (0, 1, 3):
+        assert rel_err(absolute_to_relative_camera(extr, idx), g[f"relative_{idx}"]) < 1e-6
+
+
+def test_scheduler_tables_bit_exact(golden):
+    from mv_ldm_amd.scheduler import DDIMScheduler, DDIMSchedulerCfg, SchedulerCfg, get_scheduler
+    g = golden("g6_ddim")
+    s = get_scheduler(SchedulerCfg(name="ddim", kwargs=DDIMSchedulerCfg(clip_sample=False)))
+    assert isinstance(s, DDIMScheduler) and s.init_noise_sigma == 1.0
+    assert np.array_equal(s.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    for n in (5, 25, 50, 70):
+        s.set_timesteps(n)
+        assert s.timesteps.dtype == torch.int64 and np.array_equal(s.timesteps.numpy(), g[f"timesteps_{n}"])
+    s.set_timesteps(50)
+    tab = s.coefficient_table()
+    assert tab.shape == (50, 4) and tab.dtype == torch.float32
+    ac = s.alphas_cumprod
+    assert torch.equal(tab[0], torch.stack([(1 - ac[980]) ** 0.5, ac[980] ** 0.5, ac[960] ** 0.5, (1 - ac[960]) ** 0.5]))
+    assert float(tab[-1, 2]) == 1.0 and float(tab[-1, 3]) == 0.0          # final step: alpha_prev = 1 (set_alpha_to_one)
+    x, e = torch.from_numpy(g["kat_x"]), torch.from_numpy(g["kat_eps"])
+    assert np.array_equal(s.add_noise(x, e, torch.tensor([10, 900])).numpy(), g["kat_add_noise"])
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(clip_sample=True)
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly without a GPU, never compute on the CPU"""
+    from mv_ldm_amd.modules import Conv2d, GroupNorm
+    from mv_ldm_amd.scheduler import DDIMScheduler
+    with pytest.raises(RuntimeError, match="no CPU fallback|only on a HIP device"):
+        Conv2d(8, 8, 3, padding=1)(torch.zeros(1, 8, 4, 4))
+    with pytest.raises(RuntimeError):
+        GroupNorm(4, 8)(torch.zeros(1, 8, 4, 4))
+    s = DDIMScheduler(clip_sample=False)
+    s.set_timesteps(5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        s.step(torch.zeros(1, 4), 800, torch.zeros(1, 4))
+
+
+def test_oracle_is_not_imported_by_the_product():
+    import pathlib
+    import re
+    root = pathlib.Path(__file__).resolve().parent.parent / "mv_ldm_amd"
+    for f in root.rglob("*.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), re.M), f
