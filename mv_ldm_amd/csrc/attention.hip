@@ -107,34 +107,53 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     const T* vbase = reinterpret_cast<const T*>(p.v) + (size_t)kv_row0 * p.ld_v + head * d;
     const int ntile = (kv_len + BKV - 1) / BKV;
 
-    for (int kt = 0; kt < ntile; ++kt) {
-        // ---- stage K and V^T tiles ----
-        for (int idx = tid; idx < BKV * NCH; idx += 256) {
+    // staging registers: chunk idx = tid + 256*j of the [64 keys][NCH chunks] tile
+    constexpr int NST = (BKV * NCH + 255) / 256;
+    Chunk<T> rk[NST], rv[NST];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int idx = tid + 256 * j;
             const int key = idx / NCH, ch = idx - key * NCH;
             const int kg = kt * BKV + key;
-            const bool ok = kg < kv_len && ch * EPC < d;
-            Chunk<T> ck, cv;
+            const bool ok = idx < BKV * NCH && kg < kv_len && ch * EPC < d;
             if (ok) {
-                ck = load_chunk<T>(kbase + (size_t)kg * p.ld_k + ch * EPC);
-                cv = load_chunk<T>(vbase + (size_t)kg * p.ld_v + ch * EPC);
+                rk[j] = load_chunk<T>(kbase + (size_t)kg * p.ld_k + ch * EPC);
+                rv[j] = load_chunk<T>(vbase + (size_t)kg * p.ld_v + ch * EPC);
             } else {
-                ck.zero();
-                cv.zero();
-            }
-            if constexpr (F32) {
-#pragma unroll
-                for (int i = 0; i < EPC; ++i) {
-                    Ks[key * KP + ch * EPC + i] = ck.e[i];
-                    Vt[(ch * EPC + i) * VP + key] = cv.e[i];
-                }
-            } else {
-                *reinterpret_cast<u32x4*>(Ks + key * KP + ch * EPC) = ck.raw;
-                const int pos = vt_pos16(key);
-#pragma unroll
-                for (int i = 0; i < EPC; ++i) Vt[(ch * EPC + i) * VP + pos] = cv.e[i];
+                rk[j].zero();
+                rv[j].zero();
             }
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < BKV * NCH) {
+                const int key = idx / NCH, ch = idx - key * NCH;
+                if constexpr (F32) {
+#pragma unroll
+                    for (int i = 0; i < EPC; ++i) {
+                        Ks[key * KP + ch * EPC + i] = rk[j].e[i];
+                        Vt[(ch * EPC + i) * VP + key] = rv[j].e[i];
+                    }
+                } else {
+                    *reinterpret_cast<u32x4*>(Ks + key * KP + ch * EPC) = rk[j].raw;
+                    const int pos = vt_pos16(key);
+#pragma unroll
+                    for (int i = 0; i < EPC; ++i) Vt[(ch * EPC + i) * VP + pos] = rv[j].e[i];
+                }
+            }
+        }
+    };
+    if (ntile > 0) load_tile(0);
+
+    for (int kt = 0; kt < ntile; ++kt) {
+        // ---- K / V^T tile kt is in registers (loaded during the previous tile's math): park it in LDS ----
+        store_tile();
         __syncthreads();
+        if (kt + 1 < ntile) load_tile(kt + 1);   // next tile's global loads fly under this tile's MFMAs
 
         // ---- S^T = K Q^T ----
         f32x16 s[2];
@@ -157,35 +176,44 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
 
         // ---- online softmax (per query = per lane column) ----
-        float mx = -INFINITY;
+        // raw scores stay unscaled: max is taken on them (scale > 0) and the scale rides in the exp2 argument,
+        // p = exp2(s*c - m*c): one fma + one exp per score.  Keys beyond kv_len exist only in the last tile.
+        if (kt == ntile - 1 && (kv_len & (BKV - 1)) != 0) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    s[kb][r] = key < kv_len ? s[kb][r] : -INFINITY;
+                }
+        }
+        float mx = s[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float sv = s[kb][r] * p.scale_log2e;
-                sv = key < kv_len ? sv : -INFINITY;
-                s[kb][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float c = p.scale_log2e;
+        const float alpha = exp2f((m_run - m_new) * c);
         m_run = m_new;
+        const float mc = -m_new * c;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[kb][r] - m_new);
+                const float pv = exp2f(fmaf(s[kb][r], c, mc));
                 s[kb][r] = pv;
                 rs += pv;
             }
         l_run = l_run * alpha + rs;
+        if (!__all(alpha == 1.0f)) {   // once the running max has settled the O rescale is skipped (wave-uniform)
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T ----
         if constexpr (F32) {
