@@ -16,7 +16,7 @@
 // v_mfma_f32_32x32x2_f32).
 //
 // LDS: K tile [64][DP+8] (pitch = odd multiple of 16 B -> conflict-free ds_read_b128 fragment
-// reads), V^T tile [DV][64+8].  Head dims are zero-padded to DP = roundup(d,16) / DV = roundup(d,32)
+// reads); V tile row-major [64][DV+16] read back transposed by ds_read_b64_tr_b16 (f32: V^T [DV][65]).  Head dims are zero-padded to DP = roundup(d,16) / DV = roundup(d,32)
 // inside LDS only -- never in HBM.
 #include <algorithm>
 
@@ -32,12 +32,24 @@ struct AttnParams {
 };
 
 template <typename T> struct AttnMma;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 template <> struct AttnMma<bf16_t> {
     using Frag = bf16x8;
+    using Half = bf16x4_t;
+    static __device__ __forceinline__ Half tr_read(const bf16_t* p) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) Half*)(p));
+    }
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct AttnMma<f16_t> {
     using Frag = f16x8;
+    using Half = f16x4_t;
+    static __device__ __forceinline__ Half tr_read(const f16_t* p) {
+        typedef __attribute__((ext_vector_type(4))) __fp16 fp16x4_b;
+        const fp16x4_b v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_b*)(p));
+        return __builtin_bit_cast(Half, v);
+    }
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
@@ -52,14 +64,22 @@ __device__ __forceinline__ int vt_pos16(int t) {
     return kb * 32 + g16 * 16 + hi * 8 + j;
 }
 
+// register budget: occupancy (waves per SIMD) is what overlaps one wave's softmax with another's MFMAs; the
+// 16-bit kernels are pinned to 4 waves/SIMD (<= 128 registers) for head dims <= 64 and 3 up to 96
 template <typename T, int DP>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (DP <= 64 ? 4 : (DP <= 96 ? 3 : 2)) : 1))
+void attention_kernel(const AttnParams p) {
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int EPC = Elt<T>::EPC;
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int NDB = DV / 32;
     constexpr int KP = F32 ? (DP + 1) : (DP + 8);     // K tile pitch (elements)
-    constexpr int VP = F32 ? (BKV + 1) : (BKV + 8);   // V^T tile pitch (elements)
+    // f32: V^T tile [DV][BKV+1].  16-bit: V stays ROW-major [BKV][DV+16] (coalesced 16-byte writes, like K) and
+    // the PV fragments are fetched with ds_read_b64_tr_b16, the LDS transpose read: inside a 16-lane group,
+    // lane i / element j receives element (i&3) of the 8-byte row piece addressed by lane 4j + (i>>2)
+    // (measured on gfx950, tools/probe/tr_probe.hip), i.e. a [4 keys][16 d] block comes back as lane = d,
+    // element = key.  Pitch = 2*DV + 32 bytes puts the 4 key rows of a group on disjoint banks.
+    constexpr int VP = F32 ? (BKV + 1) : (DV + 16);
     constexpr int NCH = DP / EPC;                      // 16-byte chunks per K/V row
     constexpr int NQ = F32 ? DP / 2 : DP / 16;         // Q fragments per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,16 +130,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     // staging registers: chunk idx = tid + 256*j of the [64 keys][NCH chunks] tile
     constexpr int NST = (BKV * NCH + 255) / 256;
     Chunk<T> rk[NST], rv[NST];
+    int st_key[NST], st_ch[NST];
+    const T* st_kp[NST];
+    const T* st_vp[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int idx = tid + 256 * j;
+        st_key[j] = idx / NCH;
+        st_ch[j] = idx - st_key[j] * NCH;
+        const bool live = idx < BKV * NCH && st_ch[j] * EPC < d;
+        if (!live) st_key[j] = 1 << 28;                       // never < kv_len: zero chunk
+        st_kp[j] = kbase + (size_t)(live ? st_key[j] : 0) * p.ld_k + st_ch[j] * EPC;
+        st_vp[j] = vbase + (size_t)(live ? st_key[j] : 0) * p.ld_v + st_ch[j] * EPC;
+    }
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < NST; ++j) {
-            const int idx = tid + 256 * j;
-            const int key = idx / NCH, ch = idx - key * NCH;
-            const int kg = kt * BKV + key;
-            const bool ok = idx < BKV * NCH && kg < kv_len && ch * EPC < d;
+            const bool ok = kt * BKV + st_key[j] < kv_len;
             if (ok) {
-                rk[j] = load_chunk<T>(kbase + (size_t)kg * p.ld_k + ch * EPC);
-                rv[j] = load_chunk<T>(vbase + (size_t)kg * p.ld_v + ch * EPC);
+                rk[j] = load_chunk<T>(st_kp[j] + (size_t)kt * BKV * p.ld_k);
+                rv[j] = load_chunk<T>(st_vp[j] + (size_t)kt * BKV * p.ld_v);
             } else {
                 rk[j].zero();
                 rv[j].zero();
@@ -131,7 +161,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         for (int j = 0; j < NST; ++j) {
             const int idx = tid + 256 * j;
             if (idx < BKV * NCH) {
-                const int key = idx / NCH, ch = idx - key * NCH;
+                const int key = idx / NCH, ch = idx - key * NCH;   // (loop-invariant: hoisted by the compiler)
                 if constexpr (F32) {
 #pragma unroll
                     for (int i = 0; i < EPC; ++i) {
@@ -140,9 +170,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                     }
                 } else {
                     *reinterpret_cast<u32x4*>(Ks + key * KP + ch * EPC) = rk[j].raw;
-                    const int pos = vt_pos16(key);
-#pragma unroll
-                    for (int i = 0; i < EPC; ++i) Vt[(ch * EPC + i) * VP + pos] = rv[j].e[i];
+                    *reinterpret_cast<u32x4*>(Vt + key * VP + ch * EPC) = rv[j].raw;
                 }
             }
         }
@@ -159,8 +187,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            s[kb] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C of the first MFMA
             const T* krow = Ks + (kb * 32 + l31) * KP;
             if constexpr (F32) {
 #pragma unroll
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float c = p.scale_log2e;
-        const float alpha = exp2f((m_run - m_new) * c);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // raw v_exp_f32: arguments are <= 0, no denormal-range fix-up needed
         m_run = m_new;
         const float mc = -m_new * c;
         float rs = 0.f;
@@ -203,7 +230,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(fmaf(s[kb][r], c, mc));
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, mc));
                 s[kb][r] = pv;
                 rs += pv;
             }
@@ -234,12 +261,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[ks][j] = from_f32<T>(s[ks >> 1][(ks & 1) * 8 + j]);
+
+            // source piece of this lane for the transpose read: key row 4*hi + (s>>2) (+8 for the upper half of
+            // the fragment), d columns (gi&1)*16 + 4*(s&3) .. +3, with gi = lane>>4, s = lane&15
+            const int gi = lane >> 4, sl = lane & 15;
+            const T* vsrc = Vt + (4 * (gi >> 1) + (sl >> 2)) * VP + (gi & 1) * 16 + 4 * (sl & 3);
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-                const T* vrow = Vt + (db * 32 + l31) * VP;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const auto a = *reinterpret_cast<const typename AttnMma<T>::Frag*>(vrow + ks * 16 + hi * 8);
+                    const T* pa = vsrc + (ks * 16) * VP + db * 32;
+                    const auto lo = AttnMma<T>::tr_read(pa);
+                    const auto up = AttnMma<T>::tr_read(pa + 8 * VP);
+                    const typename AttnMma<T>::Frag a = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
                     o[db] = AttnMma<T>::mma(a, pf[ks], o[db]);
                 }
             }
@@ -354,8 +388,8 @@ template <typename T, int DP> static int launch_attn(const AttnParams& p, int n_
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int KP = F32 ? (DP + 1) : (DP + 8);
-    constexpr int VP = F32 ? (BKV + 1) : (BKV + 8);
-    constexpr int smem = (BKV * KP + DV * VP) * (int)sizeof(T);
+    constexpr int VP = F32 ? (BKV + 1) : (DV + 16);
+    constexpr int smem = (BKV * KP + (F32 ? DV * VP : BKV * VP)) * (int)sizeof(T);
     auto kern = attention_kernel<T, DP>;
     static bool attr_done = false;
     if (!attr_done) {
