@@ -820,10 +820,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 }
 
 // ---- host side ------------------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct TileCfg { int bm, bn, threads; };
 static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64, 128, 256}, {64, 64, 128}, {32, 64, 64},
-                                 {256, 64, 256}};   // tile 6: 64x64 wave tile, lean 16-bit loop only
-constexpr int kNumTiles = 6;
+                                 {256, 64, 256},     // tile 6: 64x64 wave tile, lean 16-bit loop only
+                                 {256, 128, 512},    // tile 7: 8 waves of 64x64 -- half the L2->LDS bytes per flop of tile 2
+                                 {128, 256, 512}};   // tile 8
+constexpr int kNumTiles = 8;
 
 // tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
 // target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
@@ -875,7 +878,7 @@ static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
 }
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
 static int launch_bl(const IgemmParams& p, hipStream_t s) {
-    const int stages = t_force_stages ? t_force_stages : (kEnvStages ? kEnvStages : 2);
+    const int stages = t_force_stages ? t_force_stages : (kEnvStages ? kEnvStages : (BM * BN >= 256 * 128 ? 3 : 2));
     if (stages >= 3 && 3 * (BM + BN) * 128 <= 160 * 1024) return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, 3>(p, s);
     return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, 2>(p, s);
 }
@@ -915,11 +918,20 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
                 if (p.use_bl) return launch_bl_any<T, 256, 64, 4, 1>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 6 needs the 16-bit block-major path");
+        case 7:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_bl_any<T, 256, 128, 4, 2>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 7 needs the 16-bit block-major path");
+        case 8:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_bl_any<T, 128, 256, 2, 4>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 8 needs the 16-bit block-major path");
         default: return set_error(MVLDM_ERR_ARG, "igemm: bad tile %d", tile);
     }
 }
 
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Pick tile + split-K.  Target: >= ~2 workgroups per CU (256 CUs) without shredding K below 4 tiles.
 static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& tile, int& splitk, size_t ws_bytes) {
@@ -928,10 +940,14 @@ static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& ti
         // measured on MI355X (tools/igemm_sweep.py, profiles/r01_igemm_sweep_*.json): the 32x64 wave tile
         // wins everywhere at these sizes (3 workgroups per CU with a 2-deep ring); 128x64 for 3x3 convs
         // and narrow N, 64x128 for wide Linear layers; tiny M gets the small tiles.
+        // Large problems are bound by the L2 -> LDS fill rate (PMC: ~18 TB/s at 43 flop/byte with 128x64
+        // tiles): the 8-wave 256x128 / 128x256 tiles halve the bytes per flop and take a 3-deep ring.  They
+        // need >= ~300 workgroups to keep 256 CUs busy (profiles/r01_igemm_sweep2_*.json).
         if (M <= 32) tile = 5;
         else if (M <= 64) tile = 4;
-        else if (d.ksize == 3 || d.n_pad < 640) tile = 2;
-        else tile = 3;
+        else if (d.ksize == 3) tile = cdiv(M, 256) * cdiv(d.n_pad, 128) >= 300 ? 7 : 2;
+        else if (d.k_pad >= 1024 && d.n_pad >= 1024 && cdiv(M, 128) * cdiv(d.n_pad, 256) >= 300) tile = 8;
+        else tile = d.n_pad < 640 ? 2 : 3;
     }
     const int tm = cdiv(M, kTiles[tile].bm), tn = cdiv(d.n_pad, kTiles[tile].bn);
     if (splitk == 0) {
@@ -988,7 +1004,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.use_bl = d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !t_force_async && !kEnvSync && !kEnvAsync &&
                b0 < 4.0e9 && b1 < 4.0e9 && bw < 4.0e9;
     p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
-    if (tile == 6 && !p.use_bl) tile = 2;
+    if (tile >= 6 && !p.use_bl) tile = 2;
     p.splitk = splitk;
     if (p.use_bl) {   // splits own whole channel blocks (all taps of a block stay together)
         const int cbs = p.k_tiles / p.taps;

@@ -46,7 +46,7 @@ for name, ni, h, c0, c1, co, k, geglu in SHAPES:
     flops = 2.0 * ni * h * h * co * (c0 + c1) * k * k
     best = None
     combos = []
-    for tile in (1, 2, 3, 4, 6):
+    for tile in (1, 2, 3, 6, 7, 8):
         for st in (2, 3):
             for sk in (1, 0):
                 combos.append((tile, st, sk, 0, 0))   # lean buffer-load loop (default for block-major K), ring depth st
