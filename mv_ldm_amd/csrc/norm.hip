@@ -111,20 +111,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
     const size_t row0 = (size_t)img * hw + r_begin;
     T* yb = y + row0 * c;
     const int c1 = c - c0;
-    for (size_t idx = tid; idx < total; idx += blockDim.x) {
-        const int cc = (int)(idx % ncc);
-        const size_t r = idx / ncc;
+    (void)total;
+    // thread -> one fixed 16-byte channel chunk column (its 8 scale/shift pairs live in registers), rows
+    // swept with a constant stride: no division in the streaming loop
+    const int nthr = blockDim.x;
+    for (int cc0 = 0; cc0 < ncc; cc0 += nthr) {
+        const int span = min(ncc - cc0, nthr);
+        const int R = max(1, nthr / span);
+        const int cc = cc0 + tid % span, rl = tid / span;
+        if (rl >= R) continue;
         const int ch0 = cc * EPC;
-        const Chunk<T> v = ch0 < c0 ? load_chunk<T>(x0 + (row0 + r) * c0 + ch0)
-                                    : load_chunk<T>(x1 + (row0 + r) * c1 + (ch0 - c0));
-        Chunk<T> o;
+        float sc[EPC], sh[EPC];
 #pragma unroll
-        for (int i = 0; i < EPC; ++i) {
-            float f = v.get(i) * s_scale[cc * EPC + i] + s_shift[cc * EPC + i];
-            if (silu) f = silu_f(f);
-            o.set(i, f);
+        for (int i = 0; i < EPC; ++i) { sc[i] = s_scale[ch0 + i]; sh[i] = s_shift[ch0 + i]; }
+        const bool first = ch0 < c0;
+        const int cs = first ? c0 : c1;
+        const T* src = (first ? x0 + ch0 : x1 + (ch0 - c0)) + row0 * cs;
+        T* dst = yb + ch0;
+        const int nrows = r_end - r_begin;
+        for (int r = rl; r < nrows; r += R) {
+            const Chunk<T> v = load_chunk<T>(src + (size_t)r * cs);
+            Chunk<T> o;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                float f = fmaf(v.get(i), sc[i], sh[i]);
+                if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
+                o.set(i, f);
+            }
+            store_chunk<T>(dst + (size_t)r * c, o);
         }
-        store_chunk<T>(yb + idx * EPC, o);
     }
 }
 
