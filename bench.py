@@ -108,18 +108,34 @@ def cpu_baseline(args, hl: int):
                       f"({total:.1f}s per 4-view sample)"}
 
 
+def pmc_traffic(args, b):
+    """HBM bytes per igemm launch from the committed rocprofv3 PMC passes of `bench.py --unet-pass-only` at this
+    configuration (profiles/README.md says how they were collected); None when no pass matches the workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+    except OSError:
+        return None
+    key = f"{args.dtype}_b{b}_res{args.res}"
+    ent = tab.get(key)
+    return None if ent is None else round(ent["families"]["igemm"]["hbm_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scenes", type=int, default=int(os.environ.get("MVLDM_BENCH_SCENES", "16")))
+    ap.add_argument("--scenes", type=int, default=int(os.environ.get("MVLDM_BENCH_SCENES", "32")))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--op-table", default=None, help="write the per-op profile (JSON) here")
+    ap.add_argument("--unet-pass-only", action="store_true",
+                    help="run ONE eager UNet+DDIM pass and exit (the population `roofline` is quoted on; used for PMC passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +180,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.unet_pass_only:
+        hl = args.res // 8
+        st = pipe._compile(b, v_c, v_t, hl, hl, dtype, args.ddim_steps)
+        st["plan"].run()
+        torch.cuda.synchronize()
+        return
+
     for _ in range(args.warmup):
         pipe.sample(batch)
     barrier()
@@ -204,7 +227,8 @@ def main():
         achieved = ig[1] / (ig[0] * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3/1x1/linear, all launches of one UNet pass)",
                            "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                           "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
+                           "traffic": pmc_traffic(args, b), "algorithmic_bytes_per_launch": round(ig[2] / max(ig[3], 1)),
                            "launches": ig[3], "avg_launch_us": round(1e3 * ig[0] / max(ig[3], 1), 2),
                            "share_of_step_time": round(ig[0] / tot_ms, 3),
                            "flops_per_pass": ig[1], "step_ms_eager_sum": round(tot_ms, 3)}

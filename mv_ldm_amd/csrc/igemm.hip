@@ -152,7 +152,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     for (int r = 0; r < 16; ++r) {
                         const int m = tm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         if (m >= p.M) continue;
-                        epilogue_store<T>(p, m, col, (acc[i][j][r] + bv) * gelu_erf_f(acc[i][j + 1][r] + bg));
+                        epilogue_store<T>(p, m, col, (acc[i][j][r] + bv) * gelu_erf_fast(acc[i][j + 1][r] + bg));
                     }
                 }
             }
@@ -216,7 +216,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + (j >> 1) * 32 + l31] =
-                            (acc[i][j][r] + bv) * gelu_erf_f(acc[i][j + 1][r] + bg) * p.out_scale;
+                            (acc[i][j][r] + bv) * gelu_erf_fast(acc[i][j + 1][r] + bg) * p.out_scale;
                 }
             }
         } else {
@@ -627,27 +627,34 @@ __device__ __forceinline__ void bl_issue_dummy(const IgemmParams& p, char* stage
                                                  kOob, 0, 0, 0);
 }
 
+// One k-sub-step (16 of the tile's 64 K values) of operand fragments, and the MFMAs that consume them.  The
+// main loop keeps TWO of these live and always has the next one's ds_reads in flight while the current
+// one's MFMAs run -- including across the ring barrier (the first fragments of tile t+1 are fetched under
+// the last MFMAs of tile t), so one wave alone covers the LDS latency instead of leaning on occupancy.
+template <typename T, int TM, int TN> struct BlFrags {
+    typename Mma<T>::Frag a[TM], b[TN];
+};
+
 template <typename T, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void bl_compute(const char* stage_base, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn,
-                                           int hi, int l31) {
+__device__ __forceinline__ void bl_load(const char* stage_base, BlFrags<T, BM / WM / 32, BN / WN / 32>& f, int kk, int wm, int wn,
+                                        int hi, int l31) {
     using M_ = Mma<T>;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const char* at = stage_base;
     const char* bt = at + BM * 128;
 #pragma unroll
-    for (int kk = 0; kk < 64 / M_::KI; ++kk) {
-        typename M_::Frag a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) f.a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
-    }
+    for (int j = 0; j < TN; ++j) f.b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
 }
 
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void bl_mma(const BlFrags<T, TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(f.a[i], f.b[j], acc[i][j]);
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams p) {
@@ -722,32 +729,52 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     // past the end of K: keep the per-wave piece count uniform (counted vmcnt) with out-of-range (zero) pieces
 #define MVLDM_BL_DUMMY(stage_) bl_issue_dummy<BM, NW, A_IT + B_IT>(p, smem + (stage_) * STAGE_BYTES, wave)
 #define MVLDM_BL_NEXT(t_, d_) (((t_) + (d_)) % TAPS)
+#define MVLDM_BL_LOAD(f_, slot_, kk_) bl_load<T, BM, BN, WM, WN>(smem + (slot_) * STAGE_BYTES, f_, kk_, wm, wn, hi, l31)
+#define MVLDM_BL_MMA(f_)                  \
+    __builtin_amdgcn_sched_barrier(0);    \
+    bl_mma<T, TM, TN>(f_, acc);           \
+    __builtin_amdgcn_sched_barrier(0);
+    // One K-tile.  On entry f0 holds (in flight) the kk=0 fragments of the tile in slot_c and tiles
+    // T+1 .. T+STAGES-1 are in the ring.  After the last fragments of tile T are read, every wave waits for
+    // its pieces of tile T+1, the barrier publishes them and retires slot_c, which is refilled with tile
+    // T+STAGES at once; the kk=0 fragments of tile T+1 are then fetched under tile T's last MFMAs.
 #define MVLDM_BL_STEP(t_)                                                                                         \
     {                                                                                                             \
-        /* my pieces of this tile landed (STAGES-2 newer tiles may still fly); my reads of the slot about to */  \
-        /* be refilled retired */                                                                                 \
+        static_assert(64 / M_::KI == 4, "four k-sub-steps per K-tile");                                          \
+        MVLDM_BL_LOAD(f1, slot_c, 1);                                                                             \
+        MVLDM_BL_MMA(f0)                                                                                          \
+        MVLDM_BL_LOAD(f0, slot_c, 2);                                                                             \
+        MVLDM_BL_MMA(f1)                                                                                          \
+        MVLDM_BL_LOAD(f1, slot_c, 3);                                                                             \
+        MVLDM_BL_MMA(f0)                                                                                          \
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * LPT) : "memory");                      \
         __builtin_amdgcn_s_barrier();                                                                             \
         {                                                                                                         \
             /* (no constexpr locals as template arguments: the host pass rejects them inside a kernel) */       \
-            const int cbn_ = cb + ((t_) + STAGES - 1) / TAPS;                                                     \
-            if (cbn_ < cb1) { MVLDM_BL_ISSUE(slot_l, cbn_, MVLDM_BL_NEXT(t_, STAGES - 1)); }                      \
-            else { MVLDM_BL_DUMMY(slot_l); }                                                                      \
+            const int cbn_ = cb + ((t_) + STAGES) / TAPS;                                                         \
+            if (cbn_ < cb1) { MVLDM_BL_ISSUE(slot_c, cbn_, MVLDM_BL_NEXT(t_, STAGES)); }                          \
+            else { MVLDM_BL_DUMMY(slot_c); }                                                                      \
         }                                                                                                         \
-        bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
         slot_c = slot_c + 1 == STAGES ? 0 : slot_c + 1;                                                           \
-        slot_l = slot_l + 1 == STAGES ? 0 : slot_l + 1;                                                           \
+        MVLDM_BL_LOAD(f0, slot_c, 0);                                                                             \
+        MVLDM_BL_MMA(f1)                                                                                          \
     }
     if (cb0 < cb1) {
-        // prologue: STAGES-1 tiles in flight
+        // prologue: fill the whole ring (STAGES tiles in flight)
+        MVLDM_BL_ISSUE(0, cb0, 0);
         {
-            MVLDM_BL_ISSUE(0, cb0, 0);
-            if constexpr (STAGES == 3) {
-                const int cbn_ = cb0 + 1 / TAPS;
-                if (cbn_ < cb1) { MVLDM_BL_ISSUE(1, cbn_, (1 % TAPS)); } else { MVLDM_BL_DUMMY(1); }
-            }
+            const int cbn_ = cb0 + 1 / TAPS;
+            if (cbn_ < cb1) { MVLDM_BL_ISSUE(1, cbn_, (1 % TAPS)); } else { MVLDM_BL_DUMMY(1); }
         }
-        int slot_c = 0, slot_l = STAGES - 1;
+        if constexpr (STAGES == 3) {
+            const int cbn_ = cb0 + 2 / TAPS;
+            if (cbn_ < cb1) { MVLDM_BL_ISSUE(2, cbn_, (2 % TAPS)); } else { MVLDM_BL_DUMMY(2); }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int slot_c = 0;
+        BlFrags<T, TM, TN> f0, f1;
+        MVLDM_BL_LOAD(f0, 0, 0);
         for (int cb = cb0; cb < cb1; ++cb) {
             MVLDM_BL_STEP(0)
             if constexpr (TAPS == 9) {
@@ -756,13 +783,21 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
             }
         }
     }
+#undef MVLDM_BL_LOAD
+#undef MVLDM_BL_MMA
 #undef MVLDM_BL_NEXT
 #undef MVLDM_BL_DUMMY
 #undef MVLDM_BL_STEP
 #undef MVLDM_BL_ISSUE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.stage_epi) igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
-    else igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
+    if constexpr (TM * TN > 4) {
+        // (the per-element fallback does not unroll at 8 accumulator blocks and would push them to scratch:
+        //  the host only picks such a tile when the staged epilogue applies)
+        igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
+    } else {
+        if (p.stage_epi) igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
+        else igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
+    }
 }
 
 // split-K: sum the fp32 partial slabs and run the same epilogue (deterministic, no atomics)
@@ -781,7 +816,7 @@ template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce
                 g += p.ws[s * slab + (size_t)m * p.n_pad + ng];
             }
             if (p.bias) { a += p.bias[col]; g += p.bias[p.n_dst + col]; }
-            v = a * gelu_erf_f(g);
+            v = a * gelu_erf_fast(g);
         } else {
             float a = 0.f;
             for (int s = 0; s < p.splitk; ++s) a += p.ws[s * slab + (size_t)m * p.n_pad + col];
@@ -825,8 +860,9 @@ struct TileCfg { int bm, bn, threads; };
 static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64, 128, 256}, {64, 64, 128}, {32, 64, 64},
                                  {256, 64, 256},     // tile 6: 64x64 wave tile, lean 16-bit loop only
                                  {256, 128, 512},    // tile 7: 8 waves of 64x64 -- half the L2->LDS bytes per flop of tile 2
-                                 {128, 256, 512}};   // tile 8
-constexpr int kNumTiles = 8;
+                                 {128, 256, 512},    // tile 8
+                                 {256, 256, 512}};   // tile 9: 8 waves of 64x128, 2-deep ring (128 KB): 128 flop per L2->LDS byte
+constexpr int kNumTiles = 9;
 
 // tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
 // target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
@@ -873,14 +909,18 @@ static thread_local int t_force_stages = 0, t_force_sync = 0, t_force_async = 0;
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES>
 static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
     static bool done = false;
-    return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES>, done, STAGES * (BM + BN) * 128,
+    // the epilogue parks one 32-row fp32 block per wave in the (then idle) ring
+    constexpr int ring = STAGES * (BM + BN) * 128, park = WM * WN * 32 * (BN / WN + 4) * 4;
+    return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES>, done, ring > park ? ring : park,
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
 static int launch_bl(const IgemmParams& p, hipStream_t s) {
-    const int stages = t_force_stages ? t_force_stages : (kEnvStages ? kEnvStages : (BM * BN >= 256 * 128 ? 3 : 2));
-    if (stages >= 3 && 3 * (BM + BN) * 128 <= 160 * 1024) return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, 3>(p, s);
-    return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, 2>(p, s);
+    // ring depth is fixed per tile (sweeps in profiles/r01_igemm_sweep*.json): the 4-wave tiles run 2-3
+    // workgroups per CU and lose more to a third slot than they gain; the 8-wave 256x128 / 128x256 tiles own
+    // the CU and take 3 slots; 256x256 only has room for 2
+    constexpr int STAGES = (BM * BN >= 256 * 128 && 3 * (BM + BN) * 128 <= 160 * 1024) ? 3 : 2;
+    return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, STAGES>(p, s);
 }
 template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(const IgemmParams& p, hipStream_t s) {
     const bool dual = p.c1 > 0;
@@ -928,6 +968,11 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
                 if (p.use_bl) return launch_bl_any<T, 128, 256, 2, 4>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 8 needs the 16-bit block-major path");
+        case 9:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_bl_any<T, 256, 256, 4, 2>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 9 needs the 16-bit block-major path");
         default: return set_error(MVLDM_ERR_ARG, "igemm: bad tile %d", tile);
     }
 }
@@ -946,6 +991,9 @@ static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& ti
         if (M <= 32) tile = 5;
         else if (M <= 64) tile = 4;
         else if (d.ksize == 3) tile = cdiv(M, 256) * cdiv(d.n_pad, 128) >= 300 ? 7 : 2;
+        else if (d.n_pad >= 768 && d.act_dtype != MVLDM_F32 && d.k_order == 1 && d.dst_dtype != MVLDM_F32 &&
+                 cdiv(M, 256) * cdiv(d.n_pad, 256) >= 300)
+            tile = 9;   // wide Linear (QKV, GEGLU): 256x256 measured +10-15 % over 128x256 / 64x128 (sweep4)
         else if (d.k_pad >= 1024 && d.n_pad >= 1024 && cdiv(M, 128) * cdiv(d.n_pad, 256) >= 300) tile = 8;
         else tile = d.n_pad < 640 ? 2 : 3;
     }
@@ -1017,6 +1065,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     }
     // LDS-staged epilogue: 16-byte rows need 8-column alignment of the 16-bit output (or a split-K slab)
     p.stage_epi = p.use_bl && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
+    if (tile == 9 && !p.stage_epi) tile = 7;   // tile 9 has no per-element epilogue
     p.tiles_m = cdiv(p.M, kTiles[tile].bm);
     p.tiles_n = cdiv(d.n_pad, kTiles[tile].bn);
     p.korder = d.k_order;

@@ -106,7 +106,7 @@ def test_conv_tiles_and_splitk(ops, dtype):
     ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
     pw = ops.pack_weight(wt.cuda(), dtype)
     xg = nhwc(x, dtype)
-    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6)
+    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6, 7, 8, 9)
     for tile in tiles:
         for sk in (1, 2, 5):
             y = ops.conv2d(xg, pw, b.cuda(), tile=tile, splitk=sk)
@@ -179,6 +179,10 @@ def test_geglu(ops, dtype, rows, c):
         y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, splitk=sk)
         assert y.shape == (rows, 4 * c)
         close(y.float().cpu().double(), ref, dtype, f"geglu splitk{sk}")
+    if dtype != torch.float32:   # the 8-wave tiles (staged epilogue only) with the GEGLU column pairing
+        for tile in (1, 7, 8, 9):
+            y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=tile)
+            close(y.float().cpu().double(), ref, dtype, f"geglu tile{tile}")
 
 
 def test_pack_weight_layout(ops):

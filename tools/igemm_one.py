@@ -5,8 +5,9 @@ import torch
 from mv_ldm_amd import ops
 idx = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 code = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-n = 36
-SH = [(n, 32, 320, 0, 320, 3, False), (n, 8, 1280, 1280, 1280, 3, False), (n, 32, 320, 0, 2560, 1, True), (n, 16, 640, 0, 640, 3, False)]
+n = int(os.environ.get('MVLDM_ONE_N', '36'))
+SH = [(n, 32, 320, 0, 320, 3, False), (n, 8, 1280, 1280, 1280, 3, False), (n, 32, 320, 0, 2560, 1, True), (n, 16, 640, 0, 640, 3, False),
+      (n, 32, 1280, 0, 320, 1, False), (n, 32, 320, 0, 320, 1, False), (n, 16, 640, 0, 5120, 1, True)]
 ni, h, c0, c1, co, k, geglu = SH[idx]
 dt = torch.bfloat16
 x = torch.randn(ni, h, h, c0, device="cuda").to(dt)

@@ -22,6 +22,11 @@ SHAPES = [  # name, n_img, h, cin, cin2, cout, ksize, geglu
     ("L0.qkv 320->960", n, 32, 320, 0, 960, 1, False),
     ("L0.ff_out 1280->320", n, 32, 1280, 0, 320, 1, False),
     ("L2.geglu 1280->10240 @8", n, 8, 1280, 0, 10240, 1, True),
+    ("L1.geglu 640->5120 @16", n, 16, 640, 0, 5120, 1, True),
+    ("L1.ff_out 2560->640 @16", n, 16, 2560, 0, 640, 1, False),
+    ("L2.conv3x3 1280->1280 @8", n, 8, 1280, 0, 1280, 3, False),
+    ("up2.conv1 1920->640 @16", n, 16, 1280, 640, 640, 3, False),
+    ("L0.to_out 320->320", n, 32, 320, 0, 320, 1, False),
 ]
 if args.quick:
     SHAPES = SHAPES[:3]
@@ -46,10 +51,8 @@ for name, ni, h, c0, c1, co, k, geglu in SHAPES:
     flops = 2.0 * ni * h * h * co * (c0 + c1) * k * k
     best = None
     combos = []
-    for tile in (1, 2, 3, 6, 7, 8):
-        for st in (2, 3):
-            for sk in (1, 0):
-                combos.append((tile, st, sk, 0, 0))   # lean buffer-load loop (default for block-major K), ring depth st
+    for tile in (1, 2, 3, 6, 7, 8, 9):
+        combos.append((tile, 0, 1, 0, 0))   # lean buffer-load loop (default for block-major K), ring depth st
     for tile in (2, 3):
         combos.append((tile, 2, 0, 0, 2))            # previous zero-page DMA loop (bit 13)
         combos.append((tile, 0, 1, 0, 1))            # register-prefetch loop (bit 12)
