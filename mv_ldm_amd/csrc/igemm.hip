@@ -618,15 +618,6 @@ __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base,
                                                  vb[it], koff, 0, 0);
 }
 
-template <int BM, int NW, int LPT>
-__device__ __forceinline__ void bl_issue_dummy(const IgemmParams& p, char* stage_base, int wave) {
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
-#pragma unroll
-    for (int it = 0; it < LPT; ++it)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(stage_base + (wave + NW * it) * 1024), 16,
-                                                 kOob, 0, 0, 0);
-}
-
 // One k-sub-step (16 of the tile's 64 K values) of operand fragments, and the MFMAs that consume them.  The
 // main loop keeps TWO of these live and always has the next one's ds_reads in flight while the current
 // one's MFMAs run -- including across the ring barrier (the first fragments of tile t+1 are fetched under
@@ -654,6 +645,20 @@ __device__ __forceinline__ void bl_mma(const BlFrags<T, TM, TN>& f, f32x16 (&acc
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(f.a[i], f.b[j], acc[i][j]);
+}
+
+// whole K-tile, fragments fetched right before use: the 4-wave tiles run 2-4 workgroups per CU and hide the LDS
+// latency with occupancy (the pipelined form above costs them registers and measured 10-20 % slower)
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void bl_compute(const char* stage_base, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn,
+                                           int hi, int l31) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+#pragma unroll
+    for (int kk = 0; kk < 64 / Mma<T>::KI; ++kk) {
+        BlFrags<T, TM, TN> f;
+        bl_load<T, BM, BN, WM, WN>(stage_base, f, kk, wm, wn, hi, l31);
+        bl_mma<T, TM, TN>(f, acc);
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES>
@@ -726,8 +731,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     //  host pass drop the kernel's stub -- free function templates instead)
 #define MVLDM_BL_ISSUE(stage_, cb_, t_) \
     bl_issue<T, BM, BN, NW, TAPS, DUAL, A_IT, B_IT, STAGES, t_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, va0, va1, vb)
-    // past the end of K: keep the per-wave piece count uniform (counted vmcnt) with out-of-range (zero) pieces
-#define MVLDM_BL_DUMMY(stage_) bl_issue_dummy<BM, NW, A_IT + B_IT>(p, smem + (stage_) * STAGE_BYTES, wave)
 #define MVLDM_BL_NEXT(t_, d_) (((t_) + (d_)) % TAPS)
 #define MVLDM_BL_LOAD(f_, slot_, kk_) bl_load<T, BM, BN, WM, WN>(smem + (slot_) * STAGE_BYTES, f_, kk_, wm, wn, hi, l31)
 #define MVLDM_BL_MMA(f_)                  \
@@ -747,30 +750,56 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         MVLDM_BL_MMA(f1)                                                                                          \
         MVLDM_BL_LOAD(f1, slot_c, 3);                                                                             \
         MVLDM_BL_MMA(f0)                                                                                          \
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * LPT) : "memory");                      \
+        /* tile T+1 must have landed: behind it only tile T+2 can be in flight (3-deep ring, and only if it */    \
+        /* exists -- nothing is issued past the end of K, so the tail drains with vmcnt(0)) */                     \
+        if (STAGES == 3 && cb + ((t_) + 2) / TAPS < cb1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
         __builtin_amdgcn_s_barrier();                                                                             \
         {                                                                                                         \
             /* (no constexpr locals as template arguments: the host pass rejects them inside a kernel) */       \
             const int cbn_ = cb + ((t_) + STAGES) / TAPS;                                                         \
             if (cbn_ < cb1) { MVLDM_BL_ISSUE(slot_c, cbn_, MVLDM_BL_NEXT(t_, STAGES)); }                          \
-            else { MVLDM_BL_DUMMY(slot_c); }                                                                      \
         }                                                                                                         \
         slot_c = slot_c + 1 == STAGES ? 0 : slot_c + 1;                                                           \
         MVLDM_BL_LOAD(f0, slot_c, 0);                                                                             \
         MVLDM_BL_MMA(f1)                                                                                          \
     }
-    if (cb0 < cb1) {
-        // prologue: fill the whole ring (STAGES tiles in flight)
+    // 4-wave tiles: 2-slot ring, one barrier per tile, fragments fetched right before use
+#define MVLDM_BL_STEP_SIMPLE(t_)                                                                                  \
+    {                                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        {                                                                                                         \
+            const int cbn_ = cb + ((t_) + 1) / TAPS;                                                              \
+            if (cbn_ < cb1) { MVLDM_BL_ISSUE(slot_c ^ 1, cbn_, MVLDM_BL_NEXT(t_, 1)); }                           \
+        }                                                                                                         \
+        bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
+        slot_c ^= 1;                                                                                              \
+    }
+    if constexpr (NW < 8) {
+        static_assert(NW == 8 || STAGES == 2, "4-wave tiles use the 2-slot ring");
+        if (cb0 < cb1) {
+            MVLDM_BL_ISSUE(0, cb0, 0);
+            int slot_c = 0;
+            for (int cb = cb0; cb < cb1; ++cb) {
+                MVLDM_BL_STEP_SIMPLE(0)
+                if constexpr (TAPS == 9) {
+                    MVLDM_BL_STEP_SIMPLE(1) MVLDM_BL_STEP_SIMPLE(2) MVLDM_BL_STEP_SIMPLE(3) MVLDM_BL_STEP_SIMPLE(4)
+                    MVLDM_BL_STEP_SIMPLE(5) MVLDM_BL_STEP_SIMPLE(6) MVLDM_BL_STEP_SIMPLE(7) MVLDM_BL_STEP_SIMPLE(8)
+                }
+            }
+        }
+    } else if (cb0 < cb1) {
+        // prologue: fill the whole ring (up to STAGES tiles in flight), wait for the first
         MVLDM_BL_ISSUE(0, cb0, 0);
-        {
-            const int cbn_ = cb0 + 1 / TAPS;
-            if (cbn_ < cb1) { MVLDM_BL_ISSUE(1, cbn_, (1 % TAPS)); } else { MVLDM_BL_DUMMY(1); }
-        }
+        const bool has1 = cb0 + 1 / TAPS < cb1, has2 = STAGES == 3 && cb0 + 2 / TAPS < cb1;
+        if (has1) { MVLDM_BL_ISSUE(1, cb0 + 1 / TAPS, (1 % TAPS)); }
         if constexpr (STAGES == 3) {
-            const int cbn_ = cb0 + 2 / TAPS;
-            if (cbn_ < cb1) { MVLDM_BL_ISSUE(2, cbn_, (2 % TAPS)); } else { MVLDM_BL_DUMMY(2); }
+            if (has2) { MVLDM_BL_ISSUE(2, cb0 + 2 / TAPS, (2 % TAPS)); }
         }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * LPT) : "memory");
+        if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (has1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int slot_c = 0;
         BlFrags<T, TM, TN> f0, f1;
@@ -783,10 +812,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
             }
         }
     }
+#undef MVLDM_BL_STEP_SIMPLE
 #undef MVLDM_BL_LOAD
 #undef MVLDM_BL_MMA
 #undef MVLDM_BL_NEXT
-#undef MVLDM_BL_DUMMY
 #undef MVLDM_BL_STEP
 #undef MVLDM_BL_ISSUE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -992,8 +1021,9 @@ static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& ti
         else if (M <= 64) tile = 4;
         else if (d.ksize == 3) tile = cdiv(M, 256) * cdiv(d.n_pad, 128) >= 300 ? 7 : 2;
         else if (d.n_pad >= 768 && d.act_dtype != MVLDM_F32 && d.k_order == 1 && d.dst_dtype != MVLDM_F32 &&
-                 cdiv(M, 256) * cdiv(d.n_pad, 256) >= 300)
-            tile = 9;   // wide Linear (QKV, GEGLU): 256x256 measured +10-15 % over 128x256 / 64x128 (sweep4)
+                 cdiv(M, 256) * cdiv(d.n_pad, 256) >= 1024)
+            tile = 9;   // wide Linear (QKV, GEGLU) with >= 4 rounds of workgroups: 256x256 measured +10-15 % over
+                        // 128x256 / 64x128 (sweep4); at 1-2 rounds its quantisation loses 2x (N=1280 at 8x8)
         else if (d.k_pad >= 1024 && d.n_pad >= 1024 && cdiv(M, 128) * cdiv(d.n_pad, 256) >= 300) tile = 8;
         else tile = d.n_pad < 640 ? 2 : 3;
     }
