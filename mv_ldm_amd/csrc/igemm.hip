@@ -588,28 +588,52 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_async_kernel(const IgemmPar
 // VALU + 16 SALU instructions per MFMA).
 constexpr unsigned kOob = 0xFFFFFFF0u;
 
+// Per-lane source addressing of the A pieces.  Without upsampling every tap of a pixel is the centre tap's
+// byte offset plus a displacement that is the same for all lanes, so a lane keeps ONE offset per piece and
+// a 9-bit validity mask; the displacement rides in the scalar offset of the buffer load (the descriptor's
+// base is moved back by one row + one pixel so that it is never negative).  Nearest-2x upsampling makes the
+// displacement depend on the parity of the lane's pixel: those (few) launches keep a per-tap table.
+template <int TAPS, int A_IT, bool DUAL, bool UPS> struct BlAddr {
+    unsigned a0[UPS ? TAPS : 1][A_IT];
+    unsigned a1[DUAL ? (UPS ? TAPS : 1) : 1][DUAL ? A_IT : 1];
+    unsigned mask[UPS ? 1 : A_IT];
+};
+
 // issue K-tile (channel block cb, tap t) into the ring slot at `stage_base`
 // (STAGES is carried only to give every kernel instantiation its own copy: sharing one specialization
 //  between two kernels trips the host pass of hipcc 7.2)
-template <typename T, int BM, int BN, int NW, int TAPS, bool DUAL, int A_IT, int B_IT, int STAGES, int t>
+template <typename T, int BM, int BN, int NW, int KS, bool DUAL, int A_IT, int B_IT, int STAGES, bool UPS, int t>
 __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base, int wave, int cb,
-                                         const unsigned (&va0)[TAPS][A_IT], const unsigned (&va1)[DUAL ? TAPS : 1][DUAL ? A_IT : 1],
-                                         const unsigned (&vb)[B_IT]) {
-    constexpr int BK = 64;
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.src0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DUAL ? p.src1 : p.src0), 0,
-                                                                         DUAL ? p.src1_bytes : p.src0_bytes, 0x00020000);
+                                         const BlAddr<KS * KS, A_IT, DUAL, UPS>& ad, const unsigned (&vb)[B_IT]) {
+    constexpr int BK = 64, TAPS = KS * KS;
+    const int lead = (!UPS && KS == 3) ? p.w_in + 1 : 0;                                        // pixels
+    const int disp = UPS ? 0 : (t / KS - KS / 2) * p.w_in + (t % KS - KS / 2) + lead;           // >= 0
+    const unsigned lead0 = (unsigned)lead * (unsigned)p.c0 * 2u, lead1 = (unsigned)lead * (unsigned)p.c1 * 2u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.src0)) - lead0, 0, p.src0_bytes + lead0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(DUAL ? p.src1 : p.src0)) - (DUAL ? lead1 : lead0), 0,
+        DUAL ? p.src1_bytes + lead1 : p.src0_bytes + lead0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
     char* at = stage_base;
     char* bt = at + BM * 128;
     const int c = cb * BK;
     const bool from0 = !DUAL || c < p.c0;
-    const int soff = (from0 ? c : c - p.c0) * 2;
+    const int soff = ((from0 ? c : c - p.c0) + disp * (from0 ? p.c0 : p.c1)) * 2;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024);
-        if (from0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, va0[t][it], soff, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, va1[DUAL ? t : 0][DUAL ? it : 0], soff, 0, 0);
+        unsigned v0, v1;
+        if constexpr (UPS) {
+            v0 = ad.a0[t][it];
+            v1 = ad.a1[DUAL ? t : 0][DUAL ? it : 0];
+        } else {
+            const bool ok = (ad.mask[it] >> t) & 1u;
+            v0 = ok ? ad.a0[0][it] : kOob;
+            v1 = ok ? ad.a1[0][DUAL ? it : 0] : kOob;
+        }
+        if (from0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, dst, 16, v0, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, dst, 16, v1, soff, 0, 0);
     }
     const int koff = (cb * TAPS + t) * (BK * 2);
 #pragma unroll
@@ -661,7 +685,7 @@ __device__ __forceinline__ void bl_compute(const char* stage_base, f32x16 (&acc)
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES, bool UPS>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams p) {
     using M_ = Mma<T>;
     static_assert(sizeof(T) == 2, "16-bit activation types only");
@@ -685,29 +709,39 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     const int cb1 = min(cb0 + p.k_tiles_per_split / TAPS, p.k_tiles / TAPS);
 
     const int slot = lane & 7, rsub = lane >> 3;
-    const unsigned hs = p.upsample ? 2 * p.h_in : p.h_in, wsz = p.upsample ? 2 * p.w_in : p.w_in;
-    const int ups = p.upsample ? 1 : 0;
-    unsigned va0[TAPS][A_IT], va1[DUAL ? TAPS : 1][DUAL ? A_IT : 1];
+    BlAddr<TAPS, A_IT, DUAL, UPS> ad;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int row = (wave + NW * it) * 8 + rsub;
         const int m = tm * BM + row;
         const unsigned chunk = (unsigned)((slot ^ ((row >> 1) & 7)) * EPC);
-        int pix0 = 0, y0 = -(1 << 20), x0 = 0;
-        if (m < p.M) {
-            const int img = m / p.hw_out, rem = m - img * p.hw_out;
-            const int oy = rem / p.w_out;
-            pix0 = img * p.h_in;
-            y0 = oy * p.stride - p.pad;
-            x0 = (rem - oy * p.w_out) * p.stride - p.pad;
-        }
+        const bool live = m < p.M;
+        const int img = live ? m / p.hw_out : 0, rem = live ? m - img * p.hw_out : 0;
+        const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+        if constexpr (UPS) {
+            const unsigned hs = 2 * p.h_in, wsz = 2 * p.w_in;
+            const int y0 = live ? oy * p.stride - p.pad : -(1 << 20), x0 = ox * p.stride - p.pad;
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int iy = y0 + t / KS, ix = x0 + t % KS;
-            const bool ok = (unsigned)iy < hs && (unsigned)ix < wsz;
-            const unsigned pix = (unsigned)(pix0 + (iy >> ups)) * (unsigned)p.w_in + (unsigned)(ix >> ups);
-            va0[t][it] = ok ? (pix * (unsigned)p.c0 + chunk) * 2u : kOob;
-            if constexpr (DUAL) va1[t][it] = ok ? (pix * (unsigned)p.c1 + chunk) * 2u : kOob;
+            for (int t = 0; t < TAPS; ++t) {
+                const int iy = y0 + t / KS, ix = x0 + t % KS;
+                const bool ok = (unsigned)iy < hs && (unsigned)ix < wsz;
+                const unsigned pix = (unsigned)(img * p.h_in + (iy >> 1)) * (unsigned)p.w_in + (unsigned)(ix >> 1);
+                ad.a0[t][it] = ok ? (pix * (unsigned)p.c0 + chunk) * 2u : kOob;
+                if constexpr (DUAL) ad.a1[t][it] = ok ? (pix * (unsigned)p.c1 + chunk) * 2u : kOob;
+            }
+        } else {
+            // centre tap (inside the image for every live row: checked on the host)
+            const int yc = oy * p.stride - p.pad + KS / 2, xc = ox * p.stride - p.pad + KS / 2;
+            const unsigned pix = (unsigned)(img * p.h_in + yc) * (unsigned)p.w_in + (unsigned)xc;
+            unsigned msk = 0;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int iy = yc + t / KS - KS / 2, ix = xc + t % KS - KS / 2;
+                msk |= (live && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) ? (1u << t) : 0u;
+            }
+            ad.a0[0][it] = (pix * (unsigned)p.c0 + chunk) * 2u;
+            if constexpr (DUAL) ad.a1[0][it] = (pix * (unsigned)p.c1 + chunk) * 2u;
+            ad.mask[it] = msk;
         }
     }
     unsigned vb[B_IT];
@@ -730,7 +764,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     // (no lambdas around the buffer builtins: an opaque __amdgpu_buffer_rsrc_t inside a lambda makes the
     //  host pass drop the kernel's stub -- free function templates instead)
 #define MVLDM_BL_ISSUE(stage_, cb_, t_) \
-    bl_issue<T, BM, BN, NW, TAPS, DUAL, A_IT, B_IT, STAGES, t_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, va0, va1, vb)
+    bl_issue<T, BM, BN, NW, KS, DUAL, A_IT, B_IT, STAGES, UPS, t_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, ad, vb)
 #define MVLDM_BL_NEXT(t_, d_) (((t_) + (d_)) % TAPS)
 #define MVLDM_BL_LOAD(f_, slot_, kk_) bl_load<T, BM, BN, WM, WN>(smem + (slot_) * STAGE_BYTES, f_, kk_, wm, wn, hi, l31)
 #define MVLDM_BL_MMA(f_)                  \
@@ -935,12 +969,12 @@ static int launch_async(const IgemmParams& p, hipStream_t s) {
 // bit 13 previous (zero-page) DMA loop
 static thread_local int t_force_stages = 0, t_force_sync = 0, t_force_async = 0;
 
-template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES, bool UPS>
 static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
     static bool done = false;
     // the epilogue parks one 32-row fp32 block per wave in the (then idle) ring
     constexpr int ring = STAGES * (BM + BN) * 128, park = WM * WN * 32 * (BN / WN + 4) * 4;
-    return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES>, done, ring > park ? ring : park,
+    return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES, UPS>, done, ring > park ? ring : park,
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
@@ -948,8 +982,15 @@ static int launch_bl(const IgemmParams& p, hipStream_t s) {
     // ring depth is fixed per tile (sweeps in profiles/r01_igemm_sweep*.json): the 4-wave tiles run 2-3
     // workgroups per CU and lose more to a third slot than they gain; the 8-wave 256x128 / 128x256 tiles own
     // the CU and take 3 slots; 256x256 only has room for 2
-    constexpr int STAGES = (BM * BN >= 256 * 128 && 3 * (BM + BN) * 128 <= 160 * 1024) ? 3 : 2;
-    return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, STAGES>(p, s);
+    constexpr int STAGES = (WM * WN == 8 && 3 * (BM + BN) * 128 <= 160 * 1024) ? 3 : 2;
+    if (p.upsample) {
+        // per-tap address tables: only built for the two tiles the host maps upsampling convs to
+        if constexpr (KS == 3 && !DUAL && ((BM == 128 && BN == 64) || (BM == 256 && BN == 128)))
+            return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, STAGES, true>(p, s);
+        else
+            return set_error(MVLDM_ERR_ARG, "igemm: upsampling 3x3 conv needs tile 2 or 7 on the 16-bit path");
+    }
+    return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, STAGES, false>(p, s);
 }
 template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(const IgemmParams& p, hipStream_t s) {
     const bool dual = p.c1 > 0;
@@ -1096,6 +1137,12 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     // LDS-staged epilogue: 16-byte rows need 8-column alignment of the 16-bit output (or a split-K slab)
     p.stage_epi = p.use_bl && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
     if (tile == 9 && !p.stage_epi) tile = 7;   // tile 9 has no per-element epilogue
+    if (p.use_bl && d.upsample && tile != 7) tile = 2;
+    if (p.use_bl && !d.upsample) {
+        // the lean loop addresses every tap relative to the centre tap: it must lie inside the image
+        const int hc = (d.h_out - 1) * d.stride - d.pad + d.ksize / 2, wc = (d.w_out - 1) * d.stride - d.pad + d.ksize / 2;
+        MVLDM_REQUIRE(d.pad <= d.ksize / 2 && hc < d.h_in && wc < d.w_in, "igemm: conv geometry (pad %d, stride %d) not supported", d.pad, d.stride);
+    }
     p.tiles_m = cdiv(p.M, kTiles[tile].bm);
     p.tiles_n = cdiv(d.n_pad, kTiles[tile].bn);
     p.korder = d.k_order;
