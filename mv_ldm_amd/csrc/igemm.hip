@@ -183,87 +183,101 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
 // applied, nothing rounded yet), then re-reads it row-major: each lane owns 8 consecutive output
 // columns -> one 16-byte residual load, one rounding, one 16-byte store; a store instruction covers 8
 // full 128-byte lines.  Split-K partial slabs take the same route with 16-byte fp32 stores.
+// A wave tile wider than 4 column blocks is parked in groups of <= 4 blocks (the 8 park buffers must fit the ring).
+constexpr int park_blocks(int tn) { return tn <= 4 ? tn : 4; }
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tm,
                                                       int tn, int split, int wm, int wn, int wave, int lane, char* smem) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int WCOLS = BN / WN;          // packed columns of a wave tile
-    constexpr int PITCH = WCOLS + 4;        // floats
+    constexpr int JG = park_blocks(TN), NG = (TN + JG - 1) / JG;
+    constexpr int PITCH = JG * 32 + 4;      // floats
+    static_assert(TN <= 4 || TN % 2 == 1 || JG % 2 == 0, "GEGLU pairs must not straddle a park group");
     const int hi = lane >> 5, l31 = lane & 31;
     const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
     const bool partial = p.splitk > 1;
     float* st = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
-    const int ncol0_packed = tn * BN + wn * WCOLS;                       // first packed column of this wave
-    const int wc = (geglu && !partial) ? WCOLS / 2 : WCOLS;              // output columns held by this wave
-    const int ncol0 = (geglu && !partial) ? (ncol0_packed >> 1) : ncol0_packed;
     const int n_lim = partial ? p.n_pad : p.n_dst;
     __syncthreads();   // every wave is done with the operand ring
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        // ---- park: finished values, fp32, [row][col] ----
-        if (partial) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + j * 32 + l31] = acc[i][j][r];
-        } else if (geglu) {
-            if constexpr (TN % 2 == 0) {
-#pragma unroll
-                for (int j = 0; j < TN; j += 2) {
-                    const int col = ncol0 + (j >> 1) * 32 + l31;
-                    const float bv = (p.bias && col < p.n_dst) ? p.bias[col] : 0.f;
-                    const float bg = (p.bias && col < p.n_dst) ? p.bias[p.n_dst + col] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + (j >> 1) * 32 + l31] =
-                            (acc[i][j][r] + bv) * gelu_erf_fast(acc[i][j + 1][r] + bg) * p.out_scale;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = ncol0 + j * 32 + l31;
-                const float bv = (p.bias && n < p.n_out) ? p.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float v = acc[i][j][r] + bv;
-                    if (p.row_bias) {
-                        const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
-                        if (m < p.M && n < p.n_out) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
-                    }
-                    if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
-                    st[row * PITCH + j * 32 + l31] = v * p.out_scale;
-                }
-            }
-        }
-        // (same wave wrote and reads: LDS serves a wave's requests in order; the compiler's own lgkmcnt
-        //  wait covers the data dependence through `st`)
-        // ---- re-read row-major, 8 columns per lane ----
-        const int cpr = wc >> 3;                  // 8-column chunks per row
-        const int total = 32 * cpr;
-        for (int idx = lane; idx < total; idx += 64) {
-            const int row = idx / cpr, ch = idx - row * cpr;
-            const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
-            const int n0 = ncol0 + ch * 8;
-            if (m >= p.M || n0 >= n_lim) continue;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8 + 4);
-            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        for (int g = 0; g < NG; ++g) {
+            const int j0 = g * JG;
+            const int jn = (TN - j0) < JG ? (TN - j0) : JG;                      // column blocks in this group
+            const int gcol0_packed = tn * BN + wn * WCOLS + j0 * 32;            // first packed column of the group
+            const bool pair = geglu && !partial;
+            const int wc = pair ? jn * 16 : jn * 32;                            // output columns of the group
+            const int ncol0 = pair ? (gcol0_packed >> 1) : gcol0_packed;
+            // ---- park: finished values, fp32, [row][col] ----
             if (partial) {
-                float* o = p.ws + (size_t)split * p.M * p.n_pad + (size_t)m * p.n_pad + n0;
-                *reinterpret_cast<f32x4*>(o) = a;
-                *reinterpret_cast<f32x4*>(o + 4) = b;
-            } else {
-                if (p.residual) {
-                    const Chunk<T> rc = load_chunk<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.n_dst + n0);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rc.get(e);
+                for (int j = 0; j < JG; ++j)
+                    if (j0 + j < TN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + j * 32 + l31] = acc[i][j0 + j][r];
+                    }
+            } else if (geglu) {
+                if constexpr (TN % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < JG; j += 2)
+                        if (j0 + j < TN) {
+                            const int col = ncol0 + (j >> 1) * 32 + l31;
+                            const float bv = (p.bias && col < p.n_dst) ? p.bias[col] : 0.f;
+                            const float bg = (p.bias && col < p.n_dst) ? p.bias[p.n_dst + col] : 0.f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + (j >> 1) * 32 + l31] =
+                                    (acc[i][j0 + j][r] + bv) * gelu_erf_fast(acc[i][j0 + j + 1][r] + bg) * p.out_scale;
+                        }
                 }
-                Chunk<T> oc;
+            } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) oc.set(e, v[e]);
-                store_chunk<T>(reinterpret_cast<T*>(p.dst) + (size_t)m * p.dst_ld + n0, oc);
+                for (int j = 0; j < JG; ++j)
+                    if (j0 + j < TN) {
+                        const int n = ncol0 + j * 32 + l31;
+                        const float bv = (p.bias && n < p.n_out) ? p.bias[n] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            float v = acc[i][j0 + j][r] + bv;
+                            if (p.row_bias) {
+                                const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
+                                if (m < p.M && n < p.n_out) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
+                            }
+                            if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
+                            st[row * PITCH + j * 32 + l31] = v * p.out_scale;
+                        }
+                    }
+            }
+            // (same wave wrote and reads: LDS serves a wave's requests in order; the compiler's own lgkmcnt
+            //  wait covers the data dependence through `st`)
+            // ---- re-read row-major, 8 columns per lane ----
+            const int cpr = wc >> 3;                  // 8-column chunks per row
+            const int total = 32 * cpr;
+            for (int idx = lane; idx < total; idx += 64) {
+                const int row = idx / cpr, ch = idx - row * cpr;
+                const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
+                const int n0 = ncol0 + ch * 8;
+                if (m >= p.M || n0 >= n_lim) continue;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8 + 4);
+                float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                if (partial) {
+                    float* o = p.ws + (size_t)split * p.M * p.n_pad + (size_t)m * p.n_pad + n0;
+                    *reinterpret_cast<f32x4*>(o) = a;
+                    *reinterpret_cast<f32x4*>(o + 4) = b;
+                } else {
+                    if (p.residual) {
+                        const Chunk<T> rc = load_chunk<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.n_dst + n0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rc.get(e);
+                    }
+                    Chunk<T> oc;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) oc.set(e, v[e]);
+                    store_chunk<T>(reinterpret_cast<T*>(p.dst) + (size_t)m * p.dst_ld + n0, oc);
+                }
             }
         }
     }
@@ -810,8 +824,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
         slot_c ^= 1;                                                                                              \
     }
-    if constexpr (NW < 8) {
-        static_assert(NW == 8 || STAGES == 2, "4-wave tiles use the 2-slot ring");
+    // (the pipelined form needs 2 x (TM + TN) fragments next to the accumulators: not with 10 accumulator blocks)
+    constexpr bool PIPE = NW == 8 && TM * TN <= 8;
+    if constexpr (!PIPE) {
+        static_assert(STAGES == 2, "the plain loop uses the 2-slot ring");
         if (cb0 < cb1) {
             MVLDM_BL_ISSUE(0, cb0, 0);
             int slot_c = 0;
@@ -924,8 +940,10 @@ static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64
                                  {256, 64, 256},     // tile 6: 64x64 wave tile, lean 16-bit loop only
                                  {256, 128, 512},    // tile 7: 8 waves of 64x64 -- half the L2->LDS bytes per flop of tile 2
                                  {128, 256, 512},    // tile 8
-                                 {256, 256, 512}};   // tile 9: 8 waves of 64x128, 2-deep ring (128 KB): 128 flop per L2->LDS byte
-constexpr int kNumTiles = 9;
+                                 {256, 256, 512},    // tile 9: 8 waves of 64x128, 2-deep ring (128 KB): 128 flop per L2->LDS byte
+                                 {256, 320, 512}};   // tile 10: 8 waves of 64x160 -- every channel count of this UNet is a
+                                                     // multiple of 320 (no N padding); 142 flop per L2->LDS byte
+constexpr int kNumTiles = 10;
 
 // tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
 // target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
@@ -973,7 +991,7 @@ template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STA
 static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
     static bool done = false;
     // the epilogue parks one 32-row fp32 block per wave in the (then idle) ring
-    constexpr int ring = STAGES * (BM + BN) * 128, park = WM * WN * 32 * (BN / WN + 4) * 4;
+    constexpr int ring = STAGES * (BM + BN) * 128, park = WM * WN * 32 * (park_blocks(BN / WN / 32) * 32 + 4) * 4;
     return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES, UPS>, done, ring > park ? ring : park,
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
@@ -1043,6 +1061,11 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
                 if (p.use_bl) return launch_bl_any<T, 256, 256, 4, 2>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 9 needs the 16-bit block-major path");
+        case 10:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_bl_any<T, 256, 320, 4, 2>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 10 needs the 16-bit block-major path");
         default: return set_error(MVLDM_ERR_ARG, "igemm: bad tile %d", tile);
     }
 }
@@ -1058,7 +1081,15 @@ static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& ti
         // Large problems are bound by the L2 -> LDS fill rate (PMC: ~18 TB/s at 43 flop/byte with 128x64
         // tiles): the 8-wave 256x128 / 128x256 tiles halve the bytes per flop and take a 3-deep ring.  They
         // need >= ~300 workgroups to keep 256 CUs busy (profiles/r01_igemm_sweep2_*.json).
-        if (M <= 32) tile = 5;
+        // 256x320: no N padding at this UNet's channel counts (320/640/960/1280) and the best bytes-per-flop, but
+        // only ~1 workgroup per CU: needs whole rounds of 256 workgroups (sweep5: +14..33 % on the 32x32-level
+        // convs / Linears at 32 scenes, a loss below ~2 rounds)
+        const bool can10 = d.act_dtype != MVLDM_F32 && d.k_order == 1 && d.dst_dtype != MVLDM_F32 && d.n_pad % 320 == 0 &&
+                           d.epilogue != MVLDM_EPI_GEGLU && !d.upsample && d.n_out % 8 == 0 && (d.dst_ld <= 0 || d.dst_ld % 8 == 0);
+        const int wgs10 = cdiv(M, 256) * (d.n_pad / 320);
+        const double eff10 = (double)wgs10 / (256.0 * cdiv(wgs10, 256));
+        if (can10 && (wgs10 >= 1024 || (wgs10 >= 512 && eff10 >= 0.9))) tile = 10;
+        else if (M <= 32) tile = 5;
         else if (M <= 64) tile = 4;
         else if (d.ksize == 3) tile = cdiv(M, 256) * cdiv(d.n_pad, 128) >= 300 ? 7 : 2;
         else if (d.n_pad >= 768 && d.act_dtype != MVLDM_F32 && d.k_order == 1 && d.dst_dtype != MVLDM_F32 &&
@@ -1136,7 +1167,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     }
     // LDS-staged epilogue: 16-byte rows need 8-column alignment of the 16-bit output (or a split-K slab)
     p.stage_epi = p.use_bl && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
-    if (tile == 9 && !p.stage_epi) tile = 7;   // tile 9 has no per-element epilogue
+    if (tile >= 9 && (!p.stage_epi || (tile == 10 && d.epilogue == MVLDM_EPI_GEGLU))) tile = 7;   // no per-element epilogue there; odd TN cannot pair GEGLU columns
     if (p.use_bl && d.upsample && tile != 7) tile = 2;
     if (p.use_bl && !d.upsample) {
         // the lean loop addresses every tap relative to the centre tap: it must lie inside the image

@@ -106,7 +106,7 @@ def test_conv_tiles_and_splitk(ops, dtype):
     ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
     pw = ops.pack_weight(wt.cuda(), dtype)
     xg = nhwc(x, dtype)
-    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6, 7, 8, 9)
+    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)
     for tile in tiles:
         for sk in (1, 2, 5):
             y = ops.conv2d(xg, pw, b.cuda(), tile=tile, splitk=sk)
