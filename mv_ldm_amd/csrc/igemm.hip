@@ -957,6 +957,7 @@ static const int kEnvSync = env_int("MVLDM_IGEMM_SYNC", 0);
 static const int kEnvPx = env_int("MVLDM_IGEMM_PX", 0);
 static const int kEnvAsync = env_int("MVLDM_IGEMM_ASYNC", 0);
 static const int kEnvNoStage = env_int("MVLDM_IGEMM_NOSTAGE", 0);
+static const int kEnvFake = env_int("MVLDM_IGEMM_FAKE", 0);
 
 template <typename KernT> static int launch_kernel(KernT kern, bool& attr_done, int smem, int blocks, int threads,
                                                    const IgemmParams& p, hipStream_t s) {
@@ -1154,6 +1155,8 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.use_bl = d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !t_force_async && !kEnvSync && !kEnvAsync &&
                b0 < 4.0e9 && b1 < 4.0e9 && bw < 4.0e9;
     p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
+    if (kEnvFake & 1) p.src0_bytes = p.src1_bytes = 0;   // EXPERIMENT ONLY: every A piece fails the range check (zeros, no L2 traffic)
+    if (kEnvFake & 2) p.w_bytes = 0;                     // same for W
     if (tile >= 6 && !p.use_bl) tile = 2;
     p.splitk = splitk;
     if (p.use_bl) {   // splits own whole channel blocks (all taps of a block stay together)

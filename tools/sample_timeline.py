@@ -1,0 +1,47 @@
+"""wall-clock phases of one MVLDMPipeline.sample() (GPU).  python tools/sample_timeline.py [scenes]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import mv_ldm_amd
+from mv_ldm_amd.mvunet import MultiViewUNet, MultiViewUNetCfg
+from mv_ldm_amd.pipeline import MVLDMPipeline, SamplerCfg, ray_encode
+from mv_ldm_amd.scheduler import DDIMScheduler
+from mv_ldm_amd.vae import AutoencoderKL
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+torch.set_grad_enabled(False)
+dev = torch.device("cuda")
+mv_ldm_amd.set_compute_dtype(torch.bfloat16)
+with torch.device(dev):
+    den = MultiViewUNet(MultiViewUNetCfg(pretrained_from="stabilityai/stable-diffusion-2-1"), 11, 4)
+    vae = AutoencoderKL.from_pretrained("stabilityai/stable-diffusion-2-1")
+bench.random_init_(den, 1234); bench.random_init_(vae, 1235)
+pipe = MVLDMPipeline(den, vae, DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, 50))
+pipe.set_timesteps(50)
+batch = bench.synthetic_batch(b, 1, 4, 256, 1234, dev)
+pipe.sample(batch)
+torch.cuda.synchronize()
+
+def tick(label, t0):
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    print(f"  {label:28s} {1e3 * (t1 - t0):9.2f} ms")
+    return t1
+
+for rep in range(2):
+    print(f"sample #{rep} ({b} scenes)")
+    T0 = t = time.perf_counter()
+    ctx, tgt = batch["context"], batch["target"]
+    ctx_lat = pipe.first_stage_encode(ctx["image"]); t = tick("first_stage_encode", t)
+    bb, v_c, c, hl, wl = ctx_lat.shape
+    x_T = torch.randn((bb, 4, c, hl, wl)); t = tick("x_T randn (CPU generator)", t)
+    rays = ray_encode(ctx["extrinsics"].float(), ctx["intrinsics"].float(), tgt["extrinsics"].float(), tgt["intrinsics"].float(), hl, wl)
+    t = tick("ray_encode", t)
+    st = pipe._compile(bb, v_c, 4, hl, wl, torch.bfloat16, 50)
+    pipe.load_inputs(st, ctx_lat, x_T * pipe.scheduler.init_noise_sigma, rays, v_c); t = tick("load_inputs", t)
+    for _ in range(50):
+        st["plan"].replay()
+    t = tick("50 graph replays", t)
+    x0 = st["x_state"].view(bb, 4, hl, wl, -1).permute(0, 1, 4, 2, 3).contiguous(); t = tick("x0 gather", t)
+    img = pipe.last_stage_decode(x0); t = tick("last_stage_decode", t)
+    print(f"  {'total':28s} {1e3 * (t - T0):9.2f} ms")
