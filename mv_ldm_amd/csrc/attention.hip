@@ -28,8 +28,9 @@ struct AttnParams {
     const void* q; const void* k; const void* v; void* out;
     const int32_t* seg;
     int ld_q, ld_k, ld_v, ld_o, heads, d;
-    int nqt;   // query tiles per (head, segment) in the 1-D grid of attention_kernel
     float scale_log2e;
+    int nqt;   // query tiles per (head, segment) in the 1-D grid of attention_kernel (set at launch)
+    int remap; // 1: XCD-contiguous workgroup order (set at launch)
 };
 
 template <typename T> struct AttnMma;
@@ -89,10 +90,12 @@ void attention_kernel(const AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    // 1-D grid, query tile fastest: after the XCD remap all query tiles of one (head, segment) -- which share
-    // its K/V -- run on the same XCD and fetch K/V into that XCD's L2 once (PMC before: 2.8x the algorithmic
-    // bytes fetched, every XCD pulled every K/V)
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    // 1-D grid, query tile fastest.  For short sequences (per-view and SD self-attention, <= 2048 keys) the XCD
+    // remap puts all query tiles of one (head, segment) -- which share its K/V -- on one XCD, whose L2 then
+    // fetches K/V once (+3..9 %).  The 3-D attention (V*HW = 5120 keys at 32x32) is faster WITHOUT it (-17 %
+    // with): every CU of the XCD then streams the same 1.3 MB of K/V through the same L2 channels at once,
+    // while the round-robin order spreads 8 different (head, segment) streams over each XCD.
+    const int lid = p.remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int qt = lid % p.nqt, hs_ = lid / p.nqt;
     const int head = hs_ % p.heads;
     const int4 sg = reinterpret_cast<const int4*>(p.seg)[hs_ / p.heads];
@@ -404,6 +407,7 @@ template <typename T, int DP> static int launch_attn(AttnParams p, int n_seg, in
         attr_done = true;
     }
     p.nqt = (max_q_len + BQ - 1) / BQ;
+    p.remap = max_q_len <= 2048;
     dim3 grid(p.nqt * p.heads * n_seg);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     return check_launch();
@@ -417,7 +421,7 @@ int attention_run(const void* q, const void* k, const void* v, void* out, int ld
     MVLDM_REQUIRE(head_dim > 0 && head_dim % epc == 0, "attention: head_dim %d must be a multiple of %d", head_dim, epc);
     MVLDM_REQUIRE(ld_q % epc == 0 && ld_k % epc == 0 && ld_v % epc == 0 && ld_o % 4 == 0, "attention: row strides must keep 16-byte alignment");
     if (n_seg == 0 || max_q_len == 0) return MVLDM_OK;
-    AttnParams p{q, k, v, out, seg, ld_q, ld_k, ld_v, ld_o, heads, head_dim, scale * 1.4426950408889634f};
+    AttnParams p{q, k, v, out, seg, ld_q, ld_k, ld_v, ld_o, heads, head_dim, scale * 1.4426950408889634f, 0, 0};
     const int dp = (head_dim + 15) / 16 * 16;
     return dispatch_dtype(dtype, [&](auto t) {
         using T = decltype(t);
