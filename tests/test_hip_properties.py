@@ -1,0 +1,148 @@
+"""GPU property tests at BASELINE.json's full sizes (configs[1]: SD-2.1 topology + 9 multi-view blocks, 256x256,
+1 context + 4 target views, 50 DDIM steps) where the CPU oracle would take minutes to hours.
+
+The properties are size-independent and exact:
+  * scaling an operand by a power of two scales an implicit-GEMM / attention output by exactly that factor
+    (every product and every fp32 partial sum scales exactly; so does the final 16-bit rounding);
+  * the result for an image does not depend on where the image sits in the batch (a different workgroup /
+    tile / XCD computes it, with the same K order);
+  * the whole sampler is deterministic (no float atomics on the data path), and permuting the scenes of a
+    batch permutes the generated latents bit for bit.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mv_ldm_amd import _lib, ops as O
+    _lib.load()
+    return O
+
+
+def _randn(shape, seed, dtype, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda") * scale).to(dtype)
+
+
+# one launch per tile family at the sizes of a 32-scene UNet pass (9 images per scene)
+FULL_IGEMM = [
+    # name, n_img, h, c0, c1, n_out, ksize, geglu
+    ("L0 conv3x3 320->320 (256x320 tile)", 288, 32, 320, 0, 320, 3, False),
+    ("up3 conv1 640+320->320 dual source", 288, 32, 640, 320, 320, 3, False),
+    ("L1 conv3x3 640->640 (256x128 tile)", 288, 16, 640, 0, 640, 3, False),
+    ("L2 conv3x3 1280->1280", 288, 8, 1280, 0, 1280, 3, False),
+    ("L0 GEGLU 320->2560 (256x256 tile)", 288, 32, 320, 0, 2560, 1, True),
+    ("L0 QKV 320->960", 288, 32, 320, 0, 960, 1, False),
+    ("L3 conv3x3 1280->1280 @4x4 (split-K)", 288, 4, 1280, 0, 1280, 3, False),
+]
+
+
+@pytest.mark.parametrize("case", FULL_IGEMM, ids=[c[0] for c in FULL_IGEMM])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_igemm_full_size_scaling_and_batch_position(ops, case, dtype):
+    name, n, h, c0, c1, co, k, geglu = case
+    x = _randn((n, h, h, c0), 1, dtype)
+    x2 = _randn((n, h, h, c1), 2, dtype) if c1 else None
+    w = _randn((co, c0 + c1, k, k), 3, torch.float32, 1.0 / math.sqrt((c0 + c1) * k * k))
+    pw = ops.pack_weight(w if k == 3 else w[:, :, 0, 0], dtype, geglu=geglu, c_split=c0 if c1 else None)
+    epi = 2 if geglu else 0
+    y = ops.conv2d(x, pw, x2=x2, epilogue=epi)
+    assert torch.isfinite(y.float()).all()
+    # the same launch twice: bit-identical
+    assert torch.equal(y, ops.conv2d(x, pw, x2=x2, epilogue=epi))
+    if not geglu:   # (GELU is not homogeneous)
+        y4 = ops.conv2d(x * 4, pw, x2=None if x2 is None else x2 * 4, epilogue=epi)
+        normal = y.float().abs() >= 2.0 ** -12     # (an f16 result in the subnormal range keeps fewer bits than its 4x)
+        assert torch.equal(y4.float()[normal], (y.float() * 4)[normal]) and float(normal.float().mean()) > 0.99, name
+    # reverse the image order: every image is now computed by a different workgroup
+    idx = torch.arange(n - 1, -1, -1, device="cuda")
+    yr = ops.conv2d(x[idx].contiguous(), pw, x2=None if x2 is None else x2[idx].contiguous(), epilogue=epi)
+    assert torch.equal(yr, y[idx]), name
+    # a 2-image launch (small tiles, other split-K) agrees to rounding with the 288-image one
+    ys = ops.conv2d(x[:2].contiguous(), pw, x2=None if x2 is None else x2[:2].contiguous(), epilogue=epi)
+    err = (ys.float() - y[:2].float()).norm() / y[:2].float().norm()
+    assert err < (4e-3 if dtype == torch.bfloat16 else 5e-4), (name, float(err))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("heads,d,seq,nseg", [(5, 64, 5120, 16), (5, 64, 4096, 16), (10, 64, 256, 160), (8, 40, 5120, 8)],
+                         ids=["3d_V5_32x32", "3d_V4_32x32", "self_16x16", "mv_d40"])
+def test_attention_full_size_properties(ops, dtype, heads, d, seq, nseg):
+    C = heads * d
+    q, k, v = (_randn((nseg * seq, C), s, dtype) for s in (4, 5, 6))
+    seg = ops.make_segments([seq] * nseg)
+    o = ops.attention(q, k, v, heads, d, seg, seq)
+    assert torch.isfinite(o.float()).all()
+    assert torch.equal(o, ops.attention(q, k, v, heads, d, seg, seq))                       # deterministic
+    o2, normal = ops.attention(q, k, v * 2, heads, d, seg, seq).float(), o.float().abs() >= 2.0 ** -12
+    assert torch.equal(o2[normal], (o.float() * 2)[normal])                                # exactly linear in V
+    # rows of softmax(QK^T) sum to one: V = const  =>  O = const (to the rounding of the normalisation)
+    ones = torch.ones_like(v)
+    o1 = ops.attention(q, k, ones, heads, d, seg, seq).float()
+    assert (o1 - 1).abs().max() < (2e-2 if dtype == torch.bfloat16 else 2e-3)
+    # segments are independent: reversing their order reverses the outputs bit for bit
+    perm = torch.arange(nseg - 1, -1, -1, device="cuda").repeat_interleave(seq) * seq + torch.arange(seq, device="cuda").repeat(nseg)
+    orv = ops.attention(q[perm].contiguous(), k[perm].contiguous(), v[perm].contiguous(), heads, d, seg, seq)
+    assert torch.equal(orv, o[perm])
+
+
+def test_groupnorm_layernorm_full_size_invariances(ops):
+    dtype = torch.bfloat16
+    x = _randn((288, 32, 32, 320), 7, dtype)
+    g, b = _randn((320,), 8, torch.float32), _randn((320,), 9, torch.float32)
+    y = ops.groupnorm(x, g, b, 32, 1e-5, True)
+    assert torch.equal(y, ops.groupnorm(x, g, b, 32, 1e-5, True))             # deterministic (fp64 partials, fixed order)
+    idx = torch.arange(287, -1, -1, device="cuda")
+    assert torch.equal(ops.groupnorm(x[idx].contiguous(), g, b, 32, 1e-5, True), y[idx])
+    # statistics of the normalised tensor (no affine, no SiLU): zero mean / unit variance per (image, group)
+    one, zero = torch.ones(320, device="cuda"), torch.zeros(320, device="cuda")
+    z = ops.groupnorm(x, one, zero, 32, 1e-5, False).float().view(288, 1024, 32, 10)
+    assert z.mean(dim=(1, 3)).abs().max() < 2e-3
+    assert (z.var(dim=(1, 3), unbiased=False) - 1).abs().max() < 1e-2
+    t = x.view(-1, 320)
+    ln = ops.layernorm(t, one, zero, 1e-5).float()
+    assert ln.mean(dim=1).abs().max() < 2e-2 and (ln.var(dim=1, unbiased=False) - 1).abs().max() < 5e-2
+    assert torch.equal(ops.layernorm(t, g, b, 1e-5), ops.layernorm(t, g, b, 1e-5))
+
+
+@pytest.fixture(scope="module")
+def full_pipeline():
+    import bench
+    import mv_ldm_amd
+    from mv_ldm_amd.mvunet import MultiViewUNet, MultiViewUNetCfg
+    from mv_ldm_amd.pipeline import MVLDMPipeline, SamplerCfg
+    from mv_ldm_amd.scheduler import DDIMScheduler
+    from mv_ldm_amd.vae import AutoencoderKL
+    mv_ldm_amd.set_compute_dtype(torch.bfloat16)
+    with torch.device("cuda"):
+        den = MultiViewUNet(MultiViewUNetCfg(pretrained_from="stabilityai/stable-diffusion-2-1"), 11, 4)
+        vae = AutoencoderKL.from_pretrained("stabilityai/stable-diffusion-2-1")
+    bench.random_init_(den, 1234)
+    bench.random_init_(vae, 1235)
+    pipe = MVLDMPipeline(den, vae, DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, 50))
+    pipe.set_timesteps(50)
+    return pipe, bench
+
+
+def test_full_config_sampler_is_deterministic_and_scene_equivariant(full_pipeline):
+    """configs[1] exactly (full UNet, 256x256, 1+4 views, 50 DDIM steps, CFG 3.0), 3 scenes"""
+    pipe, bench = full_pipeline
+    b = 3
+    batch = bench.synthetic_batch(b, 1, 4, 256, 77, torch.device("cuda"))
+    x_T = torch.randn((b, 4, 4, 32, 32), generator=torch.Generator().manual_seed(5))
+    noise = torch.randn((b, 4, 32, 32), generator=torch.Generator().manual_seed(6))   # one context view per scene
+    img, x0 = pipe.sample(batch, x_T=x_T, encode_noise=noise)
+    assert img.shape == (b, 4, 3, 256, 256) and torch.isfinite(img).all() and torch.isfinite(x0).all()
+    assert float(x0.std()) > 1e-3
+    img2, x0b = pipe.sample(batch, x_T=x_T, encode_noise=noise)
+    assert torch.equal(x0, x0b) and torch.equal(img, img2)
+    perm = [2, 0, 1]
+    pb = {k: {kk: vv[perm].contiguous() for kk, vv in v.items()} for k, v in batch.items()}
+    imgp, x0p = pipe.sample(pb, x_T=x_T[perm], encode_noise=noise[perm])
+    assert torch.equal(x0p, x0[perm]) and torch.equal(imgp, img[perm])
