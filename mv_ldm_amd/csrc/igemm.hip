@@ -410,188 +410,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
     igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
 }
 
-// ---- 16-bit main loop: LDS-DMA ring -----------------------------------------------------------------
-// Same tiles, same LDS image, same MFMA consumption as igemm_kernel, but the K-tiles arrive by
-// `global_load_lds_dwordx4` (HBM/L2 -> LDS without touching VGPRs) into a ring of STAGES buffers with
-// STAGES-1 tiles in flight, so a workgroup no longer pays one global-memory latency per K-tile (the
-// 1-deep register prefetch did: ~1.5 us x K/64 per output tile).  One `s_barrier` per K-tile:
-//     wait (counted vmcnt) for MY pieces of tile t  ->  barrier  ->  issue tile t+STAGES-1 into the
-//     slot everybody just finished reading  ->  MFMAs on tile t.
-// The DMA writes LDS lane-linearly (wave base + lane*16), so the XOR swizzle of the LDS image is
-// applied to the per-lane SOURCE address instead (chunk = slot ^ ((row>>1)&7)); padding taps, rows
-// beyond M / n_pad and tiles past the K range read a 16-byte zero page.  Every iteration issues
-// exactly LPT pieces per wave, which keeps the `vmcnt` arithmetic uniform to the end of the loop.
-__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4] = {0u, 0u, 0u, 0u};
-
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_async_kernel(const IgemmParams p) {
-    using M_ = Mma<T>;
-    static_assert(sizeof(T) == 2, "LDS-DMA main loop is for the 16-bit activation types");
-    constexpr int NW = WM * WN;
-    constexpr int BK = 64, EPC = 8;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;     // 1-KiB pieces (8 rows) per wave per tile
-    constexpr int LPT = A_IT + B_IT;
-    static_assert(A_IT >= 1 && B_IT >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "bad tile");
-    static_assert((STAGES - 2) * LPT <= 63, "vmcnt immediate");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int hi = lane >> 5, l31 = lane & 31;
-
-    int split, tm, tn;
-    if (!map_block(p, split, tm, tn)) return;   // uniform per workgroup, before any barrier
-    const int kt0 = split * p.k_tiles_per_split;
-    const int kt1 = min(kt0 + p.k_tiles_per_split, p.k_tiles);
-
-    const T* zero = reinterpret_cast<const T*>(g_zero_page);
-    const int slot = lane & 7, rsub = lane >> 3;
-
-    // ---- A pieces: this lane's output pixel and a running (ky, kx, channel) cursor per piece ----
-    // (all index math is 32-bit and branch-free: it competes with the MFMAs for issue slots)
-    int a_pix0[A_IT], a_y[A_IT], a_x[A_IT], a_ky[A_IT], a_kx[A_IT], a_c[A_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int row = (wave + NW * it) * 8 + rsub;
-        const int m = tm * BM + row;
-        if (m < p.M) {
-            const int img = m / p.hw_out, rem = m - img * p.hw_out;
-            const int oy = rem / p.w_out;
-            a_pix0[it] = img * p.h_in;
-            a_y[it] = oy * p.stride - p.pad;
-            a_x[it] = (rem - oy * p.w_out) * p.stride - p.pad;
-        } else {
-            a_pix0[it] = 0; a_y[it] = -(1 << 20); a_x[it] = 0;   // always out of bounds -> zero page
-        }
-        const int kc = slot ^ ((row >> 1) & 7);
-        if (p.korder) {
-            a_c[it] = kc * EPC; a_ky[it] = 0; a_kx[it] = 0;   // chunk offset inside the 64-channel block
-        } else {
-            const int ke = kt0 * BK + kc * EPC;
-            const int tap = ke / p.ctot;
-            a_c[it] = ke - tap * p.ctot;
-            a_ky[it] = tap / p.ksize;
-            a_kx[it] = tap - a_ky[it] * p.ksize;
-        }
-    }
-    // ---- B pieces: weight row pointer (already offset to this lane's swizzled chunk) ----
-    const T* b_ptr[B_IT];
-    int b_step[B_IT];
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int row = (wave + NW * it) * 8 + rsub;
-        const int n = tn * BN + row;
-        const int kc = slot ^ ((row >> 1) & 7);
-        const bool ok = n < p.n_pad;
-        b_ptr[it] = ok ? reinterpret_cast<const T*>(p.weight) + (size_t)n * p.k_pad + (size_t)kt0 * BK + kc * EPC : zero;
-        b_step[it] = ok ? BK : 0;
-    }
-    const unsigned hs = p.upsample ? 2 * p.h_in : p.h_in, wsz = p.upsample ? 2 * p.w_in : p.w_in;
-    const int ups = p.upsample ? 1 : 0;
-    const T* s0 = reinterpret_cast<const T*>(p.src0);
-    const T* s1 = reinterpret_cast<const T*>(p.src1);
-
-    int kt_issue = kt0;   // K-tile index of the next issue (korder 1 derives tap / channel block from it)
-    auto issue_tile = [&](int stage, bool live) {
-        char* at = smem + stage * STAGE_BYTES;
-        char* bt = at + A_BYTES;
-        // korder 1: the whole K-tile is ONE tap and ONE 64-channel block of ONE source -> scalar decode
-        int u_ky = 0, u_kx = 0, u_cs = 0;
-        const T* u_base = zero;
-        if (p.korder && live) {
-            const int cb = kt_issue / p.taps, tap = kt_issue - cb * p.taps;
-            u_ky = tap / p.ksize;
-            u_kx = tap - u_ky * p.ksize;
-            const int c = cb * BK;
-            const bool from0 = c < p.c0;
-            u_cs = from0 ? p.c0 : p.c1;
-            u_base = from0 ? s0 + c : s1 + (c - p.c0);
-        }
-        ++kt_issue;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const T* src = zero;
-            if (live && p.korder) {
-                const int iy = a_y[it] + u_ky, ix = a_x[it] + u_kx;
-                const bool ok = (unsigned)iy < hs && (unsigned)ix < wsz;
-                const unsigned pix = (unsigned)(a_pix0[it] + (iy >> ups)) * (unsigned)p.w_in + (unsigned)(ix >> ups);
-                const T* ptr = u_base + (pix * (unsigned)u_cs + (unsigned)a_c[it]);
-                src = ok ? ptr : zero;
-            } else if (live) {
-                const int c = a_c[it];
-                const int iy = a_y[it] + a_ky[it], ix = a_x[it] + a_kx[it];
-                const bool ok = a_ky[it] < p.ksize && (unsigned)iy < hs && (unsigned)ix < wsz;
-                const unsigned pix = (unsigned)(a_pix0[it] + (iy >> ups)) * (unsigned)p.w_in + (unsigned)(ix >> ups);
-                const bool from0 = c < p.c0;
-                const unsigned off = from0 ? pix * (unsigned)p.c0 + (unsigned)c : pix * (unsigned)p.c1 + (unsigned)(c - p.c0);
-                const T* ptr = (from0 ? s0 : s1) + off;
-                src = ok ? ptr : zero;
-                // advance the cursor by one K-tile
-                int nc = c + BK, kx = a_kx[it], ky = a_ky[it];
-                while (nc >= p.ctot) {
-                    nc -= p.ctot;
-                    if (++kx == p.ksize) { kx = 0; ++ky; }
-                }
-                a_c[it] = nc; a_kx[it] = kx; a_ky[it] = ky;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const T* src = zero;
-            if (live) {
-                src = b_ptr[it];
-                b_ptr[it] += b_step[it];
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(bt + (wave + NW * it) * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // prologue: STAGES-1 tiles in flight
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) issue_tile(s, kt0 + s < kt1);
-
-    int st_c = 0, st_l = STAGES - 1;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        // my pieces of tile kt have landed once at most (STAGES-2) newer tiles' pieces are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
-        __builtin_amdgcn_s_barrier();   // everybody's pieces landed; everybody finished reading slot st_l
-        issue_tile(st_l, kt + STAGES - 1 < kt1);
-        const char* at = smem + st_c * STAGE_BYTES;
-        const char* bt = at + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < BK / M_::KI; ++kk) {
-            typename M_::Frag a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = M_::load(at, wm * (BM / WM) + i * 32 + l31, kk, hi);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = M_::mma(a[i], b[j], acc[i][j]);
-        }
-        st_c = st_c + 1 == STAGES ? 0 : st_c + 1;
-        st_l = st_l + 1 == STAGES ? 0 : st_l + 1;
-    }
-    // drain the (dummy) pieces still in flight before this workgroup's LDS can be handed to another one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
-}
-
 // ---- 16-bit main loop, lean form: buffer-load LDS-DMA, unrolled taps -----------------------------------
 // For the block-major K order every K-tile is (64-channel block cb, tap): the tap loop is unrolled, so each
 // lane's pixel offset for each tap is a REGISTER computed once per workgroup (out-of-image taps and rows
@@ -951,11 +769,9 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static const int kEnvStages = env_int("MVLDM_IGEMM_STAGES", 0);
 static const int kEnvTarget = env_int("MVLDM_IGEMM_TARGET", 0);
 static const int kEnvSync = env_int("MVLDM_IGEMM_SYNC", 0);
 static const int kEnvPx = env_int("MVLDM_IGEMM_PX", 0);
-static const int kEnvAsync = env_int("MVLDM_IGEMM_ASYNC", 0);
 static const int kEnvNoStage = env_int("MVLDM_IGEMM_NOSTAGE", 0);
 static const int kEnvFake = env_int("MVLDM_IGEMM_FAKE", 0);
 
@@ -977,16 +793,9 @@ template <typename T, int BM, int BN, int WM, int WN> static int launch_sync(con
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
-static int launch_async(const IgemmParams& p, hipStream_t s) {
-    static bool done = false;
-    return launch_kernel(igemm_async_kernel<T, BM, BN, WM, WN, STAGES>, done, STAGES * (BM + BN) * 128,
-                         8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
-}
-
-// per-call tuning overrides ride in the upper bits of desc.tile: bits 4-7 ring depth, 8-11 px, bit 12 sync loop,
-// bit 13 previous (zero-page) DMA loop
-static thread_local int t_force_stages = 0, t_force_sync = 0, t_force_async = 0;
+// per-call tuning overrides ride in the upper bits of desc.tile: bits 8-11 px (XCD grid), bit 12 register-prefetch
+// loop instead of the LDS-DMA one (A/B testing)
+static thread_local int t_force_sync = 0;
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES, bool UPS>
 static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
@@ -1020,18 +829,9 @@ template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(c
 template <typename T, int BM, int BN, int WM, int WN> static int launch_tile(const IgemmParams& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         if (p.use_bl) return launch_bl_any<T, BM, BN, WM, WN>(p, s);
-        if (!kEnvSync && !t_force_sync) {
-            // ring depth 2 measured best at every shape of this network: occupancy (3 workgroups per CU)
-            // hides more latency than a deeper ring that costs a resident workgroup
-            int stages = t_force_stages ? t_force_stages : kEnvStages ? kEnvStages : 2;
-            if ((BM + BN) * 128 * stages > 160 * 1024) stages = 160 * 1024 / ((BM + BN) * 128);
-            switch (stages) {
-                case 2: return launch_async<T, BM, BN, WM, WN, 2>(p, s);
-                case 3: return launch_async<T, BM, BN, WM, WN, 3>(p, s);
-                default: return launch_async<T, BM, BN, WM, WN, 4>(p, s);
-            }
-        }
     }
+    // f32, and the few 16-bit problems whose channel counts are not multiples of 64 (conv_in, VAE conv_in/out,
+    // quant convs): register-prefetch loop
     return launch_sync<T, BM, BN, WM, WN>(p, s);
 }
 
@@ -1138,9 +938,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     MVLDM_REQUIRE(p.dst_ld >= p.n_dst, "igemm: dst_ld %d < n_dst %d", p.dst_ld, p.n_dst);
     p.k_tiles = d.k_pad / bk;
     tile = d.tile & 15;
-    t_force_stages = (d.tile >> 4) & 15;
     t_force_sync = (d.tile >> 12) & 1;
-    t_force_async = (d.tile >> 13) & 1;
     const int force_px = (d.tile >> 8) & 15;
     int splitk = d.splitk;
     MVLDM_REQUIRE(tile >= 0 && tile <= kNumTiles && splitk >= 0, "igemm: tile/splitk");
@@ -1152,7 +950,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     const double es = 2.0;
     const double b0 = (double)d.n_img * d.h_in * d.w_in * d.c0 * es, b1 = (double)d.n_img * d.h_in * d.w_in * d.c1 * es;
     const double bw = (double)d.n_pad * d.k_pad * es;
-    p.use_bl = d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !t_force_async && !kEnvSync && !kEnvAsync &&
+    p.use_bl = d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !kEnvSync &&
                b0 < 4.0e9 && b1 < 4.0e9 && bw < 4.0e9;
     p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
     if (kEnvFake & 1) p.src0_bytes = p.src1_bytes = 0;   // EXPERIMENT ONLY: every A piece fails the range check (zeros, no L2 traffic)

@@ -111,8 +111,8 @@ def test_conv_tiles_and_splitk(ops, dtype):
         for sk in (1, 2, 5):
             y = ops.conv2d(xg, pw, b.cuda(), tile=tile, splitk=sk)
             close(nchw(y), ref, dtype, f"tile{tile}/splitk{sk}")
-    if dtype != torch.float32:   # the other two 16-bit main loops (bit 12: register prefetch, bit 13: zero-page DMA ring)
-        for code in (2 | (1 << 12), 2 | (1 << 13) | (3 << 4), 3 | (1 << 13) | (2 << 4)):
+    if dtype != torch.float32:   # the register-prefetch main loop on 16-bit data (bit 12), forced XCD grids (bits 8-11)
+        for code in (2 | (1 << 12), 3 | (1 << 12), 2 | (2 << 8), 7 | (4 << 8)):
             close(nchw(ops.conv2d(xg, pw, b.cuda(), tile=code, splitk=2)), ref, dtype, f"tilecode {code:#x}")
     close(nchw(ops.conv2d(xg, pw, b.cuda())), ref, dtype, "auto")
 

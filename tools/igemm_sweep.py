@@ -54,12 +54,11 @@ for name, ni, h, c0, c1, co, k, geglu in SHAPES:
     for tile in (1, 2, 3, 6, 7, 8, 9, 10):
         combos.append((tile, 0, 1, 0, 0))   # lean buffer-load loop (default for block-major K), ring depth st
     for tile in (2, 3):
-        combos.append((tile, 2, 0, 0, 2))            # previous zero-page DMA loop (bit 13)
         combos.append((tile, 0, 1, 0, 1))            # register-prefetch loop (bit 12)
     for px in (1, 2, 4, 8):
         combos.append((2, 0, 1, px, 0))
     for tile, stages, sk, px, sync in combos:
-        code = tile | (stages << 4) | (px << 8) | ((sync & 1) << 12) | ((sync >> 1) << 13)
+        code = tile | (px << 8) | ((sync & 1) << 12)
         try:
             us = timeit(lambda: ops.conv2d(x, pw, x2=x2, epilogue=2 if geglu else 0, tile=code, splitk=sk))
         except Exception as ex:

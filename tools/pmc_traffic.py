@@ -19,7 +19,7 @@ csv.field_size_limit(1 << 30)
 
 
 def family(name: str) -> str:
-    for key in ("igemm_bl_kernel", "igemm_async_kernel", "igemm_kernel", "igemm_splitk_reduce", "attention_kernel",
+    for key in ("igemm_bl_kernel", "igemm_kernel", "igemm_splitk_reduce", "attention_kernel",
                 "attention_wide_kernel", "gn_apply_kernel", "gn_stats_kernel", "layernorm_kernel", "eltwise", "ddim",
                 "timestep_embed", "pack_weight", "nchw_to_nhwc", "nhwc_to_nchw"):
         if key in name:
