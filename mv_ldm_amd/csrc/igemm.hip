@@ -34,6 +34,7 @@ struct IgemmParams {
     int tiles_m, tiles_n;
     int korder;                 // 0: k = (tap, channel)   1: k = (channel block of BK, tap, channel in block)
     int px, sub_m, sub_n, m_fast;  // XCD-aware 2-D tile partition
+    int rb_vec;                    // row_bias rows are 16-byte addressable (base and leading dimension)
     unsigned src0_bytes, src1_bytes, w_bytes;   // buffer-descriptor extents (lean 16-bit loop)
     int use_bl, stage_epi;
 };
@@ -198,6 +199,10 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x
     const bool partial = p.splitk > 1;
     float* st = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
     const int n_lim = partial ? p.n_pad : p.n_dst;
+    // the per-image bias row is added on the row-major side (8 outputs per division) unless an activation follows
+    // it or its rows are not 16-byte addressable
+    const bool rb_late = p.row_bias && !partial && p.epilogue == MVLDM_EPI_NONE && p.rb_vec;
+    const bool rb_early = p.row_bias && !partial && !rb_late;
     __syncthreads();   // every wave is done with the operand ring
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -241,7 +246,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x
                         for (int r = 0; r < 16; ++r) {
                             const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
                             float v = acc[i][j0 + j][r] + bv;
-                            if (p.row_bias) {
+                            if (rb_early) {
                                 const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
                                 if (m < p.M && n < p.n_out) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
                             }
@@ -268,6 +273,15 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x
                     *reinterpret_cast<f32x4*>(o) = a;
                     *reinterpret_cast<f32x4*>(o + 4) = b;
                 } else {
+                    if (rb_late) {   // per-image row (time embedding): one division and two 16-byte loads per 8 outputs
+                        const float* rb = p.row_bias + (size_t)(m / p.hw_out) * p.row_bias_ld + n0;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rb), r1 = *reinterpret_cast<const f32x4*>(rb + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] += r0[e] * p.out_scale;
+                            v[4 + e] += r1[e] * p.out_scale;
+                        }
+                    }
                     if (p.residual) {
                         const Chunk<T> rc = load_chunk<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.n_dst + n0);
 #pragma unroll
@@ -932,6 +946,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.ksize = d.ksize; p.stride = d.stride; p.pad = d.pad; p.upsample = d.upsample; p.taps = d.ksize * d.ksize;
     p.M = d.n_img * p.hw_out; p.n_out = d.n_out; p.n_pad = d.n_pad; p.k_pad = d.k_pad;
     p.n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
+    p.rb_vec = d.row_bias && ((uintptr_t)d.row_bias % 16 == 0) && d.row_bias_ld % 4 == 0;
     p.row_bias_ld = d.row_bias_ld; p.epilogue = d.epilogue; p.dst_f32 = d.dst_dtype == MVLDM_F32;
     p.out_scale = d.out_scale;
     p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
