@@ -35,6 +35,8 @@ struct IgemmParams {
     int korder;                 // 0: k = (tap, channel)   1: k = (channel block of BK, tap, channel in block)
     int px, sub_m, sub_n, m_fast;  // XCD-aware 2-D tile partition
     int rb_vec;                    // row_bias rows are 16-byte addressable (base and leading dimension)
+    int bias_vec;                  // bias is 16-byte aligned
+    int fake;                      // EXPERIMENT knob (MVLDM_IGEMM_FAKE): bit 2 = no global stores / residual loads, bit 3 = no epilogue
     unsigned src0_bytes, src1_bytes, w_bytes;   // buffer-descriptor extents (lean 16-bit loop)
     int use_bl, stage_epi;
 };
@@ -179,121 +181,149 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
 
 // ---- LDS-staged epilogue (16-bit loops) --------------------------------------------------------------
 // The MFMA accumulator layout gives a lane ONE column and 16 scattered rows: storing from it means 2-byte
-// stores in 64-byte runs (and the residual is read the same way).  Here every wave parks a finished
-// 32-row block of its tile in LDS as fp32 (bias / time-embedding row / SiLU / GEGLU / scale already
-// applied, nothing rounded yet), then re-reads it row-major: each lane owns 8 consecutive output
-// columns -> one 16-byte residual load, one rounding, one 16-byte store; a store instruction covers 8
-// full 128-byte lines.  Split-K partial slabs take the same route with 16-byte fp32 stores.
+// stores in 64-byte runs (and the residual is read the same way).  Here every wave parks a finished 32-row
+// block of its tile in LDS as RAW fp32 accumulators (16 ds_write_b32 per block, nothing else), then re-reads it
+// row-major: a lane owns 8 consecutive output columns of one row, so bias, time-embedding row and residual
+// arrive as 16/32-byte loads, the activation / GEGLU product runs on 8 values at a time, and one 16-byte store
+// leaves; a store instruction covers 8 full 128-byte lines.  The epilogue mode is decided once per group,
+// outside the element loops (the first version branched and waited on a bias load per accumulator block: PMC /
+// `MVLDM_IGEMM_FAKE=8` showed the epilogue costing as much as the whole main loop at K = 320).  Split-K partial
+// slabs take the same route with 16-byte fp32 stores.
 // A wave tile wider than 4 column blocks is parked in groups of <= 4 blocks (the 8 park buffers must fit the ring).
 constexpr int park_blocks(int tn) { return tn <= 4 ? tn : 4; }
+
+enum { EPI_PLAIN = 0, EPI_ACT_SILU = 1, EPI_PAIR_GEGLU = 2, EPI_PARTIAL = 3 };
+
+// one parked group: JN column blocks of one 32-row block.  m0: global row of block row 0; pcol0: first packed
+// column of the group.
+template <typename T, int JN, int MODE, int PITCH>
+__device__ __forceinline__ void epi_rows(const IgemmParams& p, const float* st, int m0, int pcol0, int split, int lane) {
+    constexpr bool PAIR = MODE == EPI_PAIR_GEGLU;
+    constexpr int WC = PAIR ? JN * 16 : JN * 32;      // output columns of the group
+    constexpr int CPR = WC / 8;                       // 8-column chunks per row
+    static_assert(64 % CPR == 0 && (32 * CPR) % 64 == 0, "row-major mapping");
+    constexpr int RSTEP = 64 / CPR, ITERS = 32 / RSTEP;
+    const int ch = lane % CPR, row0 = lane / CPR;     // a lane keeps its columns over the rows it visits
+    const int ncol0 = PAIR ? (pcol0 >> 1) : pcol0;
+    const int n0 = ncol0 + ch * 8;
+    const int n_lim = MODE == EPI_PARTIAL ? p.n_pad : p.n_dst;
+    if (n0 >= n_lim) return;
+    // value (and, for GEGLU, gate) position of this lane's chunk inside a parked row
+    const int voff = PAIR ? (2 * (ch >> 2)) * 32 + (ch & 3) * 8 : ch * 8;
+    float bv[8], bg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = bg[e] = 0.f;
+    if (MODE != EPI_PARTIAL && p.bias) {
+        if (p.bias_vec) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0), b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+            if constexpr (PAIR) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.bias + p.n_dst + n0);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.bias + p.n_dst + n0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bg[e] = g0[e]; bg[4 + e] = g1[e]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bv[e] = p.bias[n0 + e];
+                if constexpr (PAIR) bg[e] = p.bias[p.n_dst + n0 + e];
+            }
+        }
+    }
+    const bool rb_on = MODE != EPI_PARTIAL && MODE != EPI_PAIR_GEGLU && p.row_bias != nullptr;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int row = row0 + it * RSTEP;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(st + row * PITCH + voff);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(st + row * PITCH + voff + 4);
+        if constexpr (MODE == EPI_PARTIAL) {
+            float* o = p.ws + (size_t)split * p.M * p.n_pad + (size_t)m * p.n_pad + n0;
+            *reinterpret_cast<f32x4*>(o) = a;
+            *reinterpret_cast<f32x4*>(o + 4) = b;
+        } else {
+            float v[8] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3], b[0] + bv[4], b[1] + bv[5], b[2] + bv[6], b[3] + bv[7]};
+            if constexpr (PAIR) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(st + row * PITCH + voff + 32);
+                const f32x4 gb = *reinterpret_cast<const f32x4*>(st + row * PITCH + voff + 36);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] *= gelu_erf_fast(ga[e] + bg[e]);
+                    v[4 + e] *= gelu_erf_fast(gb[e] + bg[4 + e]);
+                }
+            } else {
+                if (rb_on) {   // per-image row (time embedding): one division per 8 outputs
+                    const float* rb = p.row_bias + (size_t)(m / p.hw_out) * p.row_bias_ld + n0;
+                    if (p.rb_vec) {
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rb), r1 = *reinterpret_cast<const f32x4*>(rb + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rb[e];
+                    }
+                }
+                if constexpr (MODE == EPI_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+            if (p.fake & 4) { if (v[0] == 1.2345e33f) p.ws[0] = v[1]; continue; }
+            if (p.residual) {
+                const Chunk<T> rc = load_chunk<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.n_dst + n0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rc.get(e);
+            }
+            Chunk<T> oc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oc.set(e, v[e]);
+            store_chunk<T>(reinterpret_cast<T*>(p.dst) + (size_t)m * p.dst_ld + n0, oc);
+        }
+    }
+}
+
+template <typename T, int TN, int J0, int JN, int PITCH>
+__device__ __forceinline__ void epi_group(const IgemmParams& p, const f32x16 (&accrow)[TN], float* st, int m0, int pcol0, int split,
+                                          int mode, int lane) {
+    const int hi = lane >> 5, l31 = lane & 31;
+    // ---- park: raw accumulators, fp32, [row][col] ----
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + j * 32 + l31] = accrow[J0 + j][r];
+    // (same wave wrote and reads: LDS serves a wave's requests in order; the compiler's own lgkmcnt wait covers
+    //  the data dependence through `st`)
+    if (mode == EPI_PARTIAL) epi_rows<T, JN, EPI_PARTIAL, PITCH>(p, st, m0, pcol0, split, lane);
+    else if (mode == EPI_PAIR_GEGLU) {
+        if constexpr (JN % 2 == 0) epi_rows<T, JN, EPI_PAIR_GEGLU, PITCH>(p, st, m0, pcol0, split, lane);
+    } else if (mode == EPI_ACT_SILU) epi_rows<T, JN, EPI_ACT_SILU, PITCH>(p, st, m0, pcol0, split, lane);
+    else epi_rows<T, JN, EPI_PLAIN, PITCH>(p, st, m0, pcol0, split, lane);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tm,
                                                       int tn, int split, int wm, int wn, int wave, int lane, char* smem) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int WCOLS = BN / WN;          // packed columns of a wave tile
-    constexpr int JG = park_blocks(TN), NG = (TN + JG - 1) / JG;
+    constexpr int JG = park_blocks(TN);
     constexpr int PITCH = JG * 32 + 4;      // floats
-    static_assert(TN <= 4 || TN % 2 == 1 || JG % 2 == 0, "GEGLU pairs must not straddle a park group");
-    const int hi = lane >> 5, l31 = lane & 31;
-    const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
-    const bool partial = p.splitk > 1;
+    static_assert(TN <= 2 * JG, "at most two park groups");
+    if (p.fake & 8) return;
     float* st = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
-    const int n_lim = partial ? p.n_pad : p.n_dst;
-    // the per-image bias row is added on the row-major side (8 outputs per division) unless an activation follows
-    // it or its rows are not 16-byte addressable
-    const bool rb_late = p.row_bias && !partial && p.epilogue == MVLDM_EPI_NONE && p.rb_vec;
-    const bool rb_early = p.row_bias && !partial && !rb_late;
+    const int mode = p.splitk > 1 ? EPI_PARTIAL
+                                  : (p.epilogue == MVLDM_EPI_GEGLU ? EPI_PAIR_GEGLU : (p.epilogue == MVLDM_EPI_SILU ? EPI_ACT_SILU : EPI_PLAIN));
     __syncthreads();   // every wave is done with the operand ring
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int j0 = g * JG;
-            const int jn = (TN - j0) < JG ? (TN - j0) : JG;                      // column blocks in this group
-            const int gcol0_packed = tn * BN + wn * WCOLS + j0 * 32;            // first packed column of the group
-            const bool pair = geglu && !partial;
-            const int wc = pair ? jn * 16 : jn * 32;                            // output columns of the group
-            const int ncol0 = pair ? (gcol0_packed >> 1) : gcol0_packed;
-            // ---- park: finished values, fp32, [row][col] ----
-            if (partial) {
-#pragma unroll
-                for (int j = 0; j < JG; ++j)
-                    if (j0 + j < TN) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + j * 32 + l31] = acc[i][j0 + j][r];
-                    }
-            } else if (geglu) {
-                if constexpr (TN % 2 == 0) {
-#pragma unroll
-                    for (int j = 0; j < JG; j += 2)
-                        if (j0 + j < TN) {
-                            const int col = ncol0 + (j >> 1) * 32 + l31;
-                            const float bv = (p.bias && col < p.n_dst) ? p.bias[col] : 0.f;
-                            const float bg = (p.bias && col < p.n_dst) ? p.bias[p.n_dst + col] : 0.f;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + (j >> 1) * 32 + l31] =
-                                    (acc[i][j0 + j][r] + bv) * gelu_erf_fast(acc[i][j0 + j + 1][r] + bg) * p.out_scale;
-                        }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < JG; ++j)
-                    if (j0 + j < TN) {
-                        const int n = ncol0 + j * 32 + l31;
-                        const float bv = (p.bias && n < p.n_out) ? p.bias[n] : 0.f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            float v = acc[i][j0 + j][r] + bv;
-                            if (rb_early) {
-                                const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
-                                if (m < p.M && n < p.n_out) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
-                            }
-                            if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
-                            st[row * PITCH + j * 32 + l31] = v * p.out_scale;
-                        }
-                    }
-            }
-            // (same wave wrote and reads: LDS serves a wave's requests in order; the compiler's own lgkmcnt
-            //  wait covers the data dependence through `st`)
-            // ---- re-read row-major, 8 columns per lane ----
-            const int cpr = wc >> 3;                  // 8-column chunks per row
-            const int total = 32 * cpr;
-            for (int idx = lane; idx < total; idx += 64) {
-                const int row = idx / cpr, ch = idx - row * cpr;
-                const int m = tm * BM + wm * (BM / WM) + i * 32 + row;
-                const int n0 = ncol0 + ch * 8;
-                if (m >= p.M || n0 >= n_lim) continue;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(st + row * PITCH + ch * 8 + 4);
-                float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                if (partial) {
-                    float* o = p.ws + (size_t)split * p.M * p.n_pad + (size_t)m * p.n_pad + n0;
-                    *reinterpret_cast<f32x4*>(o) = a;
-                    *reinterpret_cast<f32x4*>(o + 4) = b;
-                } else {
-                    if (rb_late) {   // per-image row (time embedding): one division and two 16-byte loads per 8 outputs
-                        const float* rb = p.row_bias + (size_t)(m / p.hw_out) * p.row_bias_ld + n0;
-                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rb), r1 = *reinterpret_cast<const f32x4*>(rb + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] += r0[e] * p.out_scale;
-                            v[4 + e] += r1[e] * p.out_scale;
-                        }
-                    }
-                    if (p.residual) {
-                        const Chunk<T> rc = load_chunk<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.n_dst + n0);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += rc.get(e);
-                    }
-                    Chunk<T> oc;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) oc.set(e, v[e]);
-                    store_chunk<T>(reinterpret_cast<T*>(p.dst) + (size_t)m * p.dst_ld + n0, oc);
-                }
-            }
-        }
+        const int m0 = tm * BM + wm * (BM / WM) + i * 32;
+        const int pcol0 = tn * BN + wn * WCOLS;
+        epi_group<T, TN, 0, JG, PITCH>(p, acc[i], st, m0, pcol0, split, mode, lane);
+        if constexpr (TN > JG) epi_group<T, TN, JG, TN - JG, PITCH>(p, acc[i], st, m0, pcol0 + JG * 32, split, mode, lane);
     }
 }
 
@@ -947,6 +977,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.M = d.n_img * p.hw_out; p.n_out = d.n_out; p.n_pad = d.n_pad; p.k_pad = d.k_pad;
     p.n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
     p.rb_vec = d.row_bias && ((uintptr_t)d.row_bias % 16 == 0) && d.row_bias_ld % 4 == 0;
+    p.bias_vec = d.bias && ((uintptr_t)d.bias % 16 == 0);
     p.row_bias_ld = d.row_bias_ld; p.epilogue = d.epilogue; p.dst_f32 = d.dst_dtype == MVLDM_F32;
     p.out_scale = d.out_scale;
     p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
@@ -968,6 +999,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.use_bl = d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !kEnvSync &&
                b0 < 4.0e9 && b1 < 4.0e9 && bw < 4.0e9;
     p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
+    p.fake = kEnvFake;
     if (kEnvFake & 1) p.src0_bytes = p.src1_bytes = 0;   // EXPERIMENT ONLY: every A piece fails the range check (zeros, no L2 traffic)
     if (kEnvFake & 2) p.w_bytes = 0;                     // same for W
     if (tile >= 6 && !p.use_bl) tile = 2;

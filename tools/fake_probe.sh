@@ -1,5 +1,6 @@
 #!/bin/bash
-# EXPERIMENT: how fast is the main loop when the operand pieces never touch L2 (range-check zeros)?
-for f in 0 3; do
+# EXPERIMENT: MVLDM_IGEMM_FAKE bits: 1 = A pieces out of range (zeros, no L2 traffic), 2 = same for W,
+# 4 = no global stores / residual loads in the epilogue, 8 = no epilogue at all
+for f in "$@"; do
   MVLDM_IGEMM_FAKE=$f python tools/igemm_sweep.py --scenes 32 --out gpurun_out/fake$f.json > /dev/null 2>&1
 done
