@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scenes", type=int, default=int(os.environ.get("MVLDM_BENCH_SCENES", "32")))
+    ap.add_argument("--scenes", type=int, default=int(os.environ.get("MVLDM_BENCH_SCENES", "64")))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--res", type=int, default=256)

@@ -136,7 +136,8 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, bias=None, *, x2=None, stride=1, p
     out = torch.empty(n, ho, wo, n_dst, dtype=out_dtype or x.dtype, device=x.device)
     scratch = None
     if splitk != 1:
-        scratch = workspace(16 * n * ho * wo * pw.n_pad * 4, x.device)
+        # split-K only pays when M*N is small: the C side lowers the split count to what fits
+        scratch = workspace(min(16 * n * ho * wo * pw.n_pad * 4, 256 << 20), x.device)
     d = igemm_desc(x, x2, pw, out, n_img=n, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, pad=pad,
                    upsample=upsample, bias=bias, row_bias=row_bias, residual=residual, epilogue=epilogue,
                    out_scale=out_scale, ws=scratch, splitk=splitk, tile=tile)
