@@ -933,7 +933,8 @@ static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& ti
                            d.epilogue != MVLDM_EPI_GEGLU && !d.upsample && d.n_out % 8 == 0 && (d.dst_ld <= 0 || d.dst_ld % 8 == 0);
         const int wgs10 = cdiv(M, 256) * (d.n_pad / 320);
         const double eff10 = (double)wgs10 / (256.0 * cdiv(wgs10, 256));
-        if (can10 && (wgs10 >= 1024 || (wgs10 >= 512 && eff10 >= 0.9))) tile = 10;
+        // (Linears keep winning down to 2 ragged rounds: 908 vs 850 TFLOP/s at 576 workgroups; 3x3 convs do not)
+        if (can10 && (wgs10 >= 1024 || (wgs10 >= 512 && (eff10 >= 0.9 || d.ksize == 1)))) tile = 10;
         else if (M <= 32) tile = 5;
         else if (M <= 64) tile = 4;
         else if (d.ksize == 3) tile = cdiv(M, 256) * cdiv(d.n_pad, 128) >= 300 ? 7 : 2;

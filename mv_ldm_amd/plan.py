@@ -14,6 +14,7 @@ torch is only the allocator here (`torch.empty`) and the owner of the HIP stream
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -262,9 +263,68 @@ class Builder:
         return dst
 
     # ---- finish ---------------------------------------------------------------------------------
-    def finalize(self) -> "Plan":
+    def finalize(self, autotune: Optional[bool] = None) -> "Plan":
         assert self.record
+        if autotune is None:
+            autotune = os.environ.get("MVLDM_AUTOTUNE", "1") != "0"
+        if autotune and torch.device(self.device).type == "cuda":
+            autotune_igemm(self.ops)
         return Plan(self.ops, self.meta, self.keep, self.device)
+
+
+# ---- plan-time tile selection ---------------------------------------------------------------------------
+# `choose_config` in igemm.hip picks a tile from the problem size with rules distilled from sweeps; which of
+# the 8-wave tiles wins near a boundary depends on whole rounds of 256 workgroups, N padding and the XCD
+# partition.  When a plan is recorded every large implicit-GEMM launch is therefore timed once per candidate
+# tile on its own buffers (they hold scratch at that point) and the fastest is frozen into the descriptor.
+# Results are cached per problem signature for the life of the process.  MVLDM_AUTOTUNE=0 keeps the rules.
+_TUNE_CACHE = {}
+_TUNE_TILES = (0, 1, 2, 3, 6, 7, 8, 9, 10)
+
+
+def _igemm_signature(d) -> tuple:
+    return (d.n_img, d.h_in, d.w_in, d.h_out, d.w_out, d.c0, d.c1, d.ksize, d.stride, d.pad, d.upsample, d.n_out, d.n_pad,
+            d.k_pad, d.epilogue, d.act_dtype, d.dst_dtype, d.k_order, d.dst_ld, bool(d.residual), bool(d.row_bias),
+            bool(d.bias), d.splitk, d.workspace_bytes)
+
+
+def autotune_igemm(ops, min_rows: int = 2048, iters: int = 3) -> int:
+    """set `desc.tile` of every auto-tiled 16-bit block-major igemm op with >= `min_rows` output rows to the
+    fastest candidate; returns the number of distinct problems timed"""
+    lib = L.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timed = 0
+    for op in ops:
+        if op.kind != L.OP_IGEMM:
+            continue
+        d = op.u.igemm
+        if d.tile != 0 or d.act_dtype == L.F32 or d.k_order != 1 or d.n_img * d.h_out * d.w_out < min_rows:
+            continue
+        key = _igemm_signature(d)
+        best = _TUNE_CACHE.get(key)
+        if best is None:
+            trial = L.Op()
+            C.memmove(C.byref(trial), C.byref(op), C.sizeof(L.Op))
+            results = []
+            for tile in _TUNE_TILES:
+                trial.u.igemm.tile = tile
+                if lib.mvldm_op_run(C.byref(trial), stream) != 0:      # candidate not applicable to this problem
+                    continue
+                e0.record()
+                for _ in range(iters):
+                    lib.mvldm_op_run(C.byref(trial), stream)
+                e1.record()
+                e1.synchronize()
+                results.append((e0.elapsed_time(e1), tile))
+            # keep the rules' choice unless a candidate is clearly (>3 %) faster: timing noise must not flip tiles
+            t_rule = next(t for t, tile in results if tile == 0)
+            t_best, tile_best = min(results)
+            best = tile_best if t_best < 0.97 * t_rule else 0
+            _TUNE_CACHE[key] = best
+            timed += 1
+        d.tile = best
+    return timed
 
 
 class Plan:

@@ -146,3 +146,29 @@ def test_full_config_sampler_is_deterministic_and_scene_equivariant(full_pipelin
     pb = {k: {kk: vv[perm].contiguous() for kk, vv in v.items()} for k, v in batch.items()}
     imgp, x0p = pipe.sample(pb, x_T=x_T[perm], encode_noise=noise[perm])
     assert torch.equal(x0p, x0[perm]) and torch.equal(imgp, img[perm])
+
+
+def test_plan_time_autotune_freezes_a_valid_tile(ops):
+    """recording a plan times every large implicit-GEMM launch per candidate tile (plan.autotune_igemm): the frozen
+    choice must be one of the candidates, be cached per problem, and leave the result unchanged to rounding"""
+    from mv_ldm_amd import plan as P
+    dtype = torch.bfloat16
+    x = _randn((36, 32, 32, 320), 11, dtype)
+    w = _randn((320, 320, 3, 3), 12, torch.float32, 1.0 / math.sqrt(2880))
+    pw = ops.pack_weight(w, dtype)
+    ref = ops.conv2d(x, pw)
+    P._TUNE_CACHE.clear()
+    outs = []
+    for tune in (True, False):
+        bld = P.Builder(x.device, dtype, record=True)
+        y = bld.conv(x, pw, name="probe")
+        y2 = bld.conv(x, pw, name="probe_again")            # same problem: served from the cache
+        plan = bld.finalize(autotune=tune)
+        if tune:
+            assert len(P._TUNE_CACHE) == 1 and next(iter(P._TUNE_CACHE.values())) in P._TUNE_TILES
+        plan.run()
+        torch.cuda.synchronize()
+        outs.append((y.clone(), y2.clone()))
+    for y, y2 in outs:
+        assert torch.equal(y, y2)
+        assert (y.float() - ref.float()).norm() / ref.float().norm() < 4e-3
