@@ -222,7 +222,9 @@ class MVLDMPipeline:
         v_t = tgt["extrinsics"].shape[1]
         if x_T is None:
             x_T = torch.randn((b, v_t, c, hl, wl))
-        rays = ray_encode(ctx["extrinsics"].float(), ctx["intrinsics"].float(), tgt["extrinsics"].float(),
-                          tgt["intrinsics"].float(), hl, wl)
-        x0 = self.denoise(ctx_lat, x_T, rays, dtype)
+        # (cameras are a few hundred floats: the per-pixel ray grid is evaluated where the latents live)
+        dev = self.device
+        cam = lambda t: t.to(dev, torch.float32)
+        rays = ray_encode(cam(ctx["extrinsics"]), cam(ctx["intrinsics"]), cam(tgt["extrinsics"]), cam(tgt["intrinsics"]), hl, wl)
+        x0 = self.denoise(ctx_lat, x_T.to(dev), rays, dtype)
         return (self.last_stage_decode(x0) if decode else None), x0

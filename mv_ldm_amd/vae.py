@@ -198,21 +198,50 @@ class AutoencoderKL(nn.Module):
         return st
 
     # ---- diffusers surface -----------------------------------------------------------------------
+    def _chunks(self, n: int, h_full: int, w_full: int, dtype) -> list:
+        """split a batch so that the largest NHWC activation of one launch (full resolution x 2*block_out_channels[0]
+        channels) stays below ~3.5 GB: the lean implicit-GEMM loop addresses its sources with 32-bit buffer
+        offsets and larger tensors fall back to the (3-5x slower) 64-bit-pointer loop.  Equal chunks when n
+        divides, so one recorded plan serves them all."""
+        es = 4 if dtype == torch.float32 else 2
+        per_img = h_full * w_full * 2 * self.config.block_out_channels[0] * es
+        cap = max(1, int(3.5e9 // per_img))
+        if n <= cap:
+            return [n]
+        k = -(-n // cap)
+        while n % k and k < n:
+            k += 1
+        size = n // k if n % k == 0 else cap
+        out = [size] * (n // size)
+        if n % size:
+            out.append(n % size)
+        return out
+
     def decode(self, z: torch.Tensor, dtype=None):
         require_gpu(z)
         n, c, h, w = z.shape
-        st = self._compile("decode", n, h, w, dtype or get_compute_dtype())
-        st["src"].copy_(z)
-        st["plan"].run()
-        return SimpleNamespace(sample=st["out"].clone())
+        dtype = dtype or get_compute_dtype()
+        outs, i0 = [], 0
+        for m in self._chunks(n, 8 * h, 8 * w, dtype):
+            st = self._compile("decode", m, h, w, dtype)
+            st["src"].copy_(z[i0:i0 + m])
+            st["plan"].run()
+            outs.append(st["out"].clone())
+            i0 += m
+        return SimpleNamespace(sample=outs[0] if len(outs) == 1 else torch.cat(outs))
 
     def encode(self, x: torch.Tensor, dtype=None):
         require_gpu(x)
         n, c, h, w = x.shape
-        st = self._compile("encode", n, h, w, dtype or get_compute_dtype())
-        st["src"].copy_(x)
-        st["plan"].run()
-        return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(st["out"].clone()))
+        dtype = dtype or get_compute_dtype()
+        outs, i0 = [], 0
+        for m in self._chunks(n, h, w, dtype):
+            st = self._compile("encode", m, h, w, dtype)
+            st["src"].copy_(x[i0:i0 + m])
+            st["plan"].run()
+            outs.append(st["out"].clone())
+            i0 += m
+        return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(outs[0] if len(outs) == 1 else torch.cat(outs)))
 
 
 @dataclass

@@ -3,7 +3,7 @@
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 bench.py ...
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py ...
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch/p_counter_collection.csv gpurun_out/pmc_write/p_counter_collection.csv out.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch/p_counter_collection.csv gpurun_out/pmc_write/p_counter_collection.csv out.json [183]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
 on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled; WRITE_SIZE is taken as reported
@@ -27,22 +27,31 @@ def family(name: str) -> str:
     return "other"
 
 
-def collect(path: str, counter: str):
-    tot, cnt = defaultdict(float), defaultdict(int)
+def collect(path: str, counter: str, igemm_last: int = 0):
+    """igemm_last > 0: keep only the last `igemm_last` igemm dispatches (the final eager UNet pass; the
+    dispatches before it are the recording pass and the plan-time tile trials)"""
+    rows = []
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
-            if row["Counter_Name"] != counter:
-                continue
-            fam = family(row["Kernel_Name"])
-            tot[fam] += float(row["Counter_Value"])
-            cnt[fam] += 1
+            if row["Counter_Name"] == counter:
+                rows.append((int(row["Dispatch_Id"]), family(row["Kernel_Name"]), float(row["Counter_Value"])))
+    rows.sort()
+    if igemm_last > 0:
+        ig = [r for r in rows if r[1] == "igemm"]
+        first_kept = ig[-igemm_last][0] if len(ig) >= igemm_last else 0
+        rows = [r for r in rows if r[0] >= first_kept]
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for _, fam, val in rows:
+        tot[fam] += val
+        cnt[fam] += 1
     return tot, cnt
 
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
-    ft, fc = collect(fetch_csv, "FETCH_SIZE")
-    wt, wc = collect(write_csv, "WRITE_SIZE")
+    igemm_last = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    ft, fc = collect(fetch_csv, "FETCH_SIZE", igemm_last)
+    wt, wc = collect(write_csv, "WRITE_SIZE", igemm_last)
     res = {}
     for fam in sorted(set(ft) | set(wt)):
         n = max(fc.get(fam, 0), wc.get(fam, 0))

@@ -35,7 +35,9 @@ for rep in range(2):
     ctx_lat = pipe.first_stage_encode(ctx["image"]); t = tick("first_stage_encode", t)
     bb, v_c, c, hl, wl = ctx_lat.shape
     x_T = torch.randn((bb, 4, c, hl, wl)); t = tick("x_T randn (CPU generator)", t)
-    rays = ray_encode(ctx["extrinsics"].float(), ctx["intrinsics"].float(), tgt["extrinsics"].float(), tgt["intrinsics"].float(), hl, wl)
+    cam = lambda t_: t_.to(dev, torch.float32)
+    rays = ray_encode(cam(ctx["extrinsics"]), cam(ctx["intrinsics"]), cam(tgt["extrinsics"]), cam(tgt["intrinsics"]), hl, wl)
+    x_T = x_T.to(dev)
     t = tick("ray_encode", t)
     st = pipe._compile(bb, v_c, 4, hl, wl, torch.bfloat16, 50)
     pipe.load_inputs(st, ctx_lat, x_T * pipe.scheduler.init_noise_sigma, rays, v_c); t = tick("load_inputs", t)
