@@ -212,10 +212,10 @@ class MVLDMPipeline:
         x0 = st["x_state"].view(b, v_t, hl, wl, -1).permute(0, 1, 4, 2, 3).contiguous()
         return x0
 
-    def sample(self, batch, x_T=None, encode_noise=None, decode: bool = True, dtype=None):
-        """diffusion_wrapper.py:455-490.  batch: {"context": {image [b,v_c,3,H,W], extrinsics, intrinsics},
-        "target": {extrinsics [b,v_t,4,4], intrinsics}}.  `x_T` / `encode_noise`: explicit noise (the
-        reference draws x_T on the CPU generator, :473)."""
+    def prepare(self, batch, x_T=None, encode_noise=None, dtype=None):
+        """everything of `sample()` before the DDIM loop: encode the context views, draw x_T, evaluate the ray
+        grid, record (or fetch) the plan and load its input buffers.  Returns the plan state at step 0."""
+        dtype = dtype or get_compute_dtype()
         ctx, tgt = batch["context"], batch["target"]
         ctx_lat = self.first_stage_encode(ctx["image"], noise=encode_noise)
         b, v_c, c, hl, wl = ctx_lat.shape
@@ -226,5 +226,19 @@ class MVLDMPipeline:
         dev = self.device
         cam = lambda t: t.to(dev, torch.float32)
         rays = ray_encode(cam(ctx["extrinsics"]), cam(ctx["intrinsics"]), cam(tgt["extrinsics"]), cam(tgt["intrinsics"]), hl, wl)
-        x0 = self.denoise(ctx_lat, x_T.to(dev), rays, dtype)
+        st = self._compile(b, v_c, v_t, hl, wl, dtype, len(self.scheduler.timesteps))
+        self.load_inputs(st, ctx_lat, x_T.to(dev) * self.scheduler.init_noise_sigma, rays, v_c)
+        return st
+
+    def sample(self, batch, x_T=None, encode_noise=None, decode: bool = True, dtype=None):
+        """diffusion_wrapper.py:455-490.  batch: {"context": {image [b,v_c,3,H,W], extrinsics, intrinsics},
+        "target": {extrinsics [b,v_t,4,4], intrinsics}}.  `x_T` / `encode_noise`: explicit noise (the
+        reference draws x_T on the CPU generator, :473)."""
+        st = self.prepare(batch, x_T, encode_noise, dtype)
+        for _ in range(len(self.scheduler.timesteps)):
+            st["plan"].replay()
+        b = batch["context"]["image"].shape[0]
+        v_t = batch["target"]["extrinsics"].shape[1]
+        hl, wl = st["x_state"].shape[1:3]
+        x0 = st["x_state"].view(b, v_t, hl, wl, -1).permute(0, 1, 4, 2, 3).contiguous()
         return (self.last_stage_decode(x0) if decode else None), x0
