@@ -216,6 +216,16 @@ def main():
         # costs less power and clocks higher (tools/sample_timeline.py)
         st = pipe.prepare(batch)
         plan = st["plan"]
+        # per-step latency of the replayed hipGraph and the UNet-only rate, on the first 10 steps
+        plan.replay(); torch.cuda.synchronize()
+        t_g = time.perf_counter()
+        for _ in range(10):
+            plan.replay()
+        torch.cuda.synchronize()
+        step_ms = 1e2 * (time.perf_counter() - t_g)
+        out["ddim_step_ms"] = round(step_ms, 3)
+        out["unet_only_views_per_s"] = round(b * v_t / (args.ddim_steps * step_ms * 1e-3), 3)
+        st = pipe.prepare(batch)
         plan.profile(1)
         ms = plan.profile(5)
         from mv_ldm_amd._lib import OP_ATTENTION, OP_GROUPNORM, OP_IGEMM, OP_LAYERNORM
@@ -226,7 +236,7 @@ def main():
         tot_ms = sum(ms)
         ig = agg.get(OP_IGEMM, [1e-9, 0, 0, 0])
         achieved = ig[1] / (ig[0] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3/1x1/linear, all launches of one UNet pass)",
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_bl_kernel (implicit-GEMM conv3x3/1x1/linear, all 183 launches of one UNet pass)",
                            "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
                            "traffic": pmc_traffic(args, b), "algorithmic_bytes_per_launch": round(ig[2] / max(ig[3], 1)),
