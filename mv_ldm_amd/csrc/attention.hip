@@ -68,9 +68,14 @@ __device__ __forceinline__ int vt_pos16(int t) {
 
 // register budget: occupancy (waves per SIMD) is what overlaps one wave's softmax with another's MFMAs; the
 // 16-bit kernels are pinned to 4 waves/SIMD (<= 128 registers) for head dims <= 64 and 3 up to 96
-template <typename T, int DP>
+// ONES (16-bit, head_dim < DP): the first zero-padding chunk of every V row holds 1.0 instead, so the PV MFMA
+// accumulates the softmax denominator sum_k p[k] in the otherwise idle output column `head_dim` -- the 32 v_add_f32
+// per tile and lane of the row sum disappear from the VALU, which is what bounds this kernel (PMC: 79 % VALU-busy,
+// 45 % MFMA-busy).  The denominator then sums the SAME rounded probabilities the numerator multiplies.
+template <typename T, int DP, bool ONES>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (DP <= 64 ? 4 : (DP <= 96 ? 3 : 2)) : 1))
 void attention_kernel(const AttnParams p) {
+    static_assert(!ONES || sizeof(T) == 2, "ones column: 16-bit kernels only");
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int EPC = Elt<T>::EPC;
     constexpr int DV = (DP + 31) / 32 * 32;
@@ -139,6 +144,7 @@ void attention_kernel(const AttnParams p) {
     constexpr int NST = (BKV * NCH + 255) / 256;
     Chunk<T> rk[NST], rv[NST];
     int st_key[NST], st_ch[NST];
+    unsigned ones_bits = 0;
     const T* st_kp[NST];
     const T* st_vp[NST];
 #pragma unroll
@@ -147,7 +153,10 @@ void attention_kernel(const AttnParams p) {
         st_key[j] = idx / NCH;
         st_ch[j] = idx - st_key[j] * NCH;
         const bool live = idx < BKV * NCH && st_ch[j] * EPC < d;
-        if (!live) st_key[j] = 1 << 28;                       // never < kv_len: zero chunk
+        if constexpr (ONES) {   // the chunk right after the head: V gets ones there (K stays zero)
+            if (idx < BKV * NCH && st_ch[j] * EPC == d) ones_bits |= 1u << j;
+        }
+        if (!live) st_key[j] = 1 << 28;                       // never < kv_len: zero (or ones) chunk
         st_kp[j] = kbase + (size_t)(live ? st_key[j] : 0) * p.ld_k + st_ch[j] * EPC;
         st_vp[j] = vbase + (size_t)(live ? st_key[j] : 0) * p.ld_v + st_ch[j] * EPC;
     }
@@ -160,7 +169,12 @@ void attention_kernel(const AttnParams p) {
                 rv[j] = load_chunk<T>(st_vp[j] + (size_t)kt * BKV * p.ld_v);
             } else {
                 rk[j].zero();
-                rv[j].zero();
+                if constexpr (ONES) {
+                    const uint32_t f = ((ones_bits >> j) & 1u) ? (std::is_same<T, bf16_t>::value ? 0x3F803F80u : 0x3C003C00u) : 0u;
+                    rv[j].raw = u32x4{f, f, f, f};
+                } else {
+                    rv[j].zero();
+                }
             }
         }
     };
@@ -240,9 +254,9 @@ void attention_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, mc));
                 s[kb][r] = pv;
-                rs += pv;
+                if constexpr (!ONES) rs += pv;
             }
-        l_run = l_run * alpha + rs;
+        if constexpr (!ONES) l_run = l_run * alpha + rs;
         if (!__all(alpha == 1.0f)) {   // once the running max has settled the O rescale is skipped (wave-uniform)
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
@@ -290,7 +304,18 @@ void attention_kernel(const AttnParams p) {
     }
 
     // ---- normalise and write O[q][d] ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (ONES) {
+        // output column d (hi = 0 lanes) / d + 4 (hi = 1 lanes) of O^T: both inside the ones chunk, both the full sum
+        l_tot = 0.f;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int q8 = 0; q8 < 4; ++q8)
+                if (db * 32 + q8 * 8 == d) l_tot = o[db][4 * q8];
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (!q_ok) return;
     T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local) * p.ld_o + head * d;
@@ -392,13 +417,13 @@ template <typename T> static int launch_attn_wide(const AttnParams& p, int n_seg
     return check_launch();
 }
 
-template <typename T, int DP> static int launch_attn(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
+template <typename T, int DP, bool ONES> static int launch_attn_k(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int KP = F32 ? (DP + 1) : (DP + 8);
     constexpr int VP = F32 ? (BKV + 1) : (DV + 16);
     constexpr int smem = (BKV * KP + (F32 ? DV * VP : BKV * VP)) * (int)sizeof(T);
-    auto kern = attention_kernel<T, DP>;
+    auto kern = attention_kernel<T, DP, ONES>;
     static bool attr_done = false;
     if (!attr_done) {
         if (smem > 48 * 1024)
@@ -411,6 +436,13 @@ template <typename T, int DP> static int launch_attn(AttnParams p, int n_seg, in
     dim3 grid(p.nqt * p.heads * n_seg);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     return check_launch();
+}
+
+template <typename T, int DP> static int launch_attn(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (p.d % 8 == 0 && p.d < DP) return launch_attn_k<T, DP, true>(p, n_seg, max_q_len, s);
+    }
+    return launch_attn_k<T, DP, false>(p, n_seg, max_q_len, s);
 }
 
 int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,
