@@ -1,6 +1,7 @@
 // GroupNorm(+SiLU) and LayerNorm for NHWC / token-major activations (see include/mvldm.h).
 //
-// GroupNorm: two launches.  (1) `gn_stats`: each workgroup streams a contiguous slab of rows of one
+// GroupNorm: ONE launch (`gn_fused_kernel`, below) when an (image, channel-span) slab fits a workgroup's registers --
+// every case of the UNet; otherwise (VAE at 256x256) two launches.  (1) `gn_stats`: each workgroup streams a contiguous slab of rows of one
 // image with 16-byte loads (fully coalesced), every thread owning one fixed 16-byte channel chunk
 // column so its per-channel sum / sum-of-squares stay in registers (fp64: the variance is exact to
 // double round-off, no E[x^2]-E[x]^2 cancellation issue), then folds channels into the 32 groups
@@ -11,6 +12,8 @@
 // LayerNorm: one wave per token row, row held in registers, two-pass mean / centred variance with
 // wave64 butterfly reductions, fp32.
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace mvldm {
 
@@ -143,6 +146,118 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
     }
 }
 
+// Single-launch GroupNorm for images whose (image, channel-span) slab fits the registers of one workgroup:
+// every thread keeps <= KT 16-byte chunks of ONE chunk column (its 8 channels belong to at most two groups), the
+// statistics are reduced through LDS (fp64), and the normalised (+SiLU) values are written from the registers --
+// the tensor is read once instead of twice (algorithmic traffic 1 read + 1 write) and one launch disappears.
+// A span is a whole number of groups and of 16-byte chunks; the host picks the widest one with <= 16 chunks per
+// thread.  Workgroups of one image are adjacent after the XCD remap (their 128-byte lines overlap).
+template <typename T, int KT>
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
+                                                        T* __restrict__ y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int hw, int c, int groups, int span,
+                                                        float eps, int silu) {
+    constexpr int EPC = Elt<T>::EPC;
+    __shared__ double s_sum[64], s_sq[64];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nspan = c / span, img = bid / nspan, sp = bid - img * nspan;
+    const int cps = span / EPC, cpg = c / groups;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int ch = tid % cps, row0 = tid / cps, rstep = nthr / cps;
+    const int col = sp * span + ch * EPC;
+    const bool first = col < c0;
+    const int cs = first ? c0 : c - c0;
+    const T* src = (first ? x0 + col : x1 + (col - c0)) + (size_t)img * hw * cs;
+    const int gbase = (sp * span) / cpg, ng = span / cpg;
+    const int g0 = col / cpg - gbase;
+    const int split = min(EPC, (gbase + g0 + 1) * cpg - col);     // elements [0, split) belong to group g0, the rest to g0 + 1
+    if (tid < 64) { s_sum[tid] = 0.0; s_sq[tid] = 0.0; }
+    __syncthreads();
+    Chunk<T> v[KT];
+    float s[EPC], q[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) { s[i] = 0.f; q[i] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int row = row0 + k * rstep;
+        if (row < hw) {
+            v[k] = load_chunk<T>(src + (size_t)row * cs);
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                const float f = v[k].get(i);
+                s[i] += f;
+                q[i] = fmaf(f, f, q[i]);
+            }
+        }
+    }
+    double sa = 0.0, qa = 0.0, sb = 0.0, qb = 0.0;
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+        if (i < split) { sa += (double)s[i]; qa += (double)q[i]; }
+        else { sb += (double)s[i]; qb += (double)q[i]; }
+    }
+    atomicAdd(&s_sum[g0], sa);
+    atomicAdd(&s_sq[g0], qa);
+    if (split < EPC) {
+        atomicAdd(&s_sum[g0 + 1], sb);
+        atomicAdd(&s_sq[g0 + 1], qb);
+    }
+    __syncthreads();
+    if (tid < ng) {
+        const double n = (double)hw * cpg;
+        const double mean = s_sum[tid] / n;
+        double var = s_sq[tid] / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+        const int g = i < split ? g0 : g0 + 1;
+        sc[i] = s_rstd[g] * gamma[col + i];
+        sh[i] = beta[col + i] - s_mean[g] * sc[i];
+    }
+    T* dst = y + (size_t)img * hw * c + col;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int row = row0 + k * rstep;
+        if (row < hw) {
+            Chunk<T> o;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                float f = fmaf(v[k].get(i), sc[i], sh[i]);
+                if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
+                o.set(i, f);
+            }
+            store_chunk<T>(dst + (size_t)row * c, o);
+        }
+    }
+}
+
+// widest span (channels) one workgroup can hold with <= 16 chunks per thread; 0: use the two-launch path
+static int gn_fused_plan(int hw, int c, int groups, int epc, int& nthr, int& kt) {
+    const int cpg = c / groups;
+    if (!((cpg >= epc && true) || (epc % cpg == 0 && epc / cpg == 2))) return 0;
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    const int base = cpg / gcd(cpg, epc) * epc;       // lcm: whole groups and whole chunks
+    if (base > c || c % base) return 0;
+    int best = 0;
+    for (int m = 1; base * m <= c; ++m) {
+        const int span = base * m;
+        if (c % span || span / cpg > 64) continue;
+        const int cps = span / epc;
+        const int l = cps / gcd(cps, 64) * 64;
+        if (l > 1024) continue;
+        const int n = 1024 / l * l;
+        const int k = (int)(((long long)hw * cps + n - 1) / n);
+        if (k <= 16) { best = span; nthr = n; kt = k; }
+    }
+    return best;
+}
+
 // ---------------------------------------------------------------------------------------------- LN
 template <typename T, int MAXCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
@@ -204,6 +319,25 @@ int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, co
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(c0 % epc == 0 && c1 % epc == 0, "groupnorm: channels (%d,%d) must be multiples of %d", c0, c1, epc);
     if (n_img == 0 || hw == 0) return MVLDM_OK;
+    static const int no_fused = getenv("MVLDM_GN_TWOPASS") ? atoi(getenv("MVLDM_GN_TWOPASS")) : 0;   // A/B knob
+    int f_nthr = 0, f_kt = 0;
+    const int f_span = no_fused ? 0 : gn_fused_plan(hw, c, groups, epc, f_nthr, f_kt);
+    if (f_span) {
+        return dispatch_dtype(dtype, [&](auto t) {
+            using T = decltype(t);
+            const dim3 grid(n_img * (c / f_span)), block(f_nthr);
+#define MVLDM_GN_FUSED(KT_)                                                                                             \
+    hipLaunchKernelGGL((gn_fused_kernel<T, KT_>), grid, block, 0, s, reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(x1), \
+                       c0, reinterpret_cast<T*>(y), gamma, beta, hw, c, groups, f_span, eps, silu)
+            if (f_kt <= 2) MVLDM_GN_FUSED(2);
+            else if (f_kt <= 4) MVLDM_GN_FUSED(4);
+            else if (f_kt <= 8) MVLDM_GN_FUSED(8);
+            else if (f_kt <= 12) MVLDM_GN_FUSED(12);
+            else MVLDM_GN_FUSED(16);
+#undef MVLDM_GN_FUSED
+            return check_launch();
+        });
+    }
     // slabs: enough workgroups to cover the chip, at least 8 rows each
     int nchunk = std::min(MVLDM_GN_MAX_CHUNKS, std::max(1, std::min(hw / 8, (1024 + n_img - 1) / n_img)));
     const int rows_per_chunk = (hw + nchunk - 1) / nchunk;
