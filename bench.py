@@ -144,13 +144,21 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # (test knobs: MVLDM_BENCH_SHARE_GPU=1 puts every rank on device 0 and MVLDM_BENCH_BACKEND=gloo replaces RCCL, so
+    #  the N > 1 launch contract can be exercised on a one-GPU box)
+    if os.environ.get("MVLDM_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("MVLDM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)      # RCCL
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # RCCL
+        else:
+            dist.init_process_group(backend)
     torch.set_grad_enabled(False)
 
     import mv_ldm_amd
@@ -195,7 +203,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     from mv_ldm_amd.dist import max_over_ranks
-    elapsed = max_over_ranks(elapsed, dev)      # the only cross-rank exchange: no data-path collective
+    elapsed = max_over_ranks(elapsed, dev if backend == "nccl" else None)      # the only cross-rank exchange: no data-path collective
     assert torch.isfinite(img).all()
     views = world * b * v_t * args.steps
     value = views / elapsed
