@@ -741,6 +741,192 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     }
 }
 
+// (buffer descriptors live in free functions, never in a kernel body: see the note at igemm_bl_kernel)
+template <bool DUAL>
+__device__ __forceinline__ void halo_issue_a(const IgemmParams& p, char* dst, unsigned v0, unsigned v1, int cb) {
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DUAL ? p.src1 : p.src0), 0,
+                                                                         DUAL ? p.src1_bytes : p.src0_bytes, 0x00020000);
+    const int c = cb * 64;
+    const bool from0 = !DUAL || c < p.c0;
+    const int soff = (from0 ? c : c - p.c0) * 2;
+    if (from0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (__attribute__((address_space(3))) void*)dst, 16, v0, soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (__attribute__((address_space(3))) void*)dst, 16, v1, soff, 0, 0);
+}
+__device__ __forceinline__ void halo_issue_w(const IgemmParams& p, char* dst, unsigned v, int koff) {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, v, koff, 0, 0);
+}
+
+// ---- 3x3 stride-1 convolution with an LDS-resident pixel halo ------------------------------------------------
+// The 9 taps of a 3x3 conv read the same 64-channel slice of the same pixels, shifted by dy*W + dx rows of the
+// NHWC pixel array.  Instead of fetching a shifted 256-row A tile per tap (9 x 32 KB per channel block through the
+// L2 -> LDS path, which bounds the loop above), this kernel fetches ONE contiguous range of
+// 256 + 2*(W+1) pixel rows per channel block (the tile's pixels plus W+1 rows of halo on either side) and serves all
+// 9 taps from it: tap (dy,dx) of tile row r is halo row r + (W+1) + dy*W + dx -- a lane-uniform displacement.
+// Image borders are per-lane 9-bit masks; a masked lane reads a 128-byte row of zeros.  Only the W tiles (16 KB per
+// tap) still stream per K-tile, through a 3-slot ring; the halo of the next channel block arrives piecewise under
+// the 9 taps of the current one (2 slots).  L2 -> LDS bytes per channel block: 41 + 9*16 = 185 KB instead of 432 KB.
+template <typename T, bool DUAL>
+__global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmParams p, int halo_rows) {
+    using M_ = Mma<T>;
+    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, NW = 8, TM = 2, TN = 2, B_IT = 2, KA = 6, EPC = 8;
+    constexpr int W_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int a_bytes = halo_rows * 128;
+    char* const wring = smem + 2 * a_bytes;
+    char* const zrow = wring + 3 * W_BYTES;
+    char* const dummy = zrow + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    int split, tm, tn;
+    if (!map_block(p, split, tm, tn)) return;
+    const int cb1 = p.k_tiles / 9;
+    const int lead = p.w_in + 1;
+    const int m0 = tm * BM;
+    const int np = halo_rows / 8;                       // 1 KiB pieces of a halo tile
+    const int slot = lane & 7, rsub = lane >> 3;
+    const int m_tot = p.n_img * p.h_in * p.w_in;
+
+    if (tid < 8) *reinterpret_cast<u32x4*>(zrow + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+
+    // halo pieces of this wave: q = wave + 8k
+    unsigned off0[KA], off1[DUAL ? KA : 1];
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        const int q = wave + NW * k;
+        const int hr = q * 8 + rsub;
+        const int pm = m0 - lead + hr;
+        const bool ok = q < np && pm >= 0 && pm < m_tot;
+        const unsigned chunk = (unsigned)((slot ^ ((hr >> 1) & 7)) * EPC);
+        off0[k] = ok ? ((unsigned)pm * (unsigned)p.c0 + chunk) * 2u : kOob;
+        if constexpr (DUAL) off1[k] = ok ? ((unsigned)pm * (unsigned)p.c1 + chunk) * 2u : kOob;
+    }
+    unsigned vb[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int row = (wave + NW * it) * 8 + rsub;
+        const int n = tn * BN + row;
+        const unsigned chunk = (unsigned)((slot ^ ((row >> 1) & 7)) * EPC);
+        vb[it] = n < p.n_pad ? ((unsigned)n * (unsigned)p.k_pad + chunk) * 2u : kOob;
+    }
+    // per-row tap validity
+    unsigned mask[TM];
+    int rloc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        rloc[i] = wm * (BM / WM) + i * 32 + l31;
+        const int m = m0 + rloc[i];
+        unsigned msk = 0;
+        if (m < p.M) {
+            const int rem = m % p.hw_out;
+            const int y = rem / p.w_out, x = rem - y * p.w_out;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                msk |= ((unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) ? (1u << t) : 0u;
+            }
+        }
+        mask[i] = msk;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one halo piece (index k of this wave) of channel block cb into halo slot cb & 1; out-of-range: zeros into `dummy`
+#define MVLDM_HALO_A(k_, cb_)                                                                                          \
+    {                                                                                                                  \
+        const int q_ = wave + NW * (k_);                                                                               \
+        const bool real_ = (cb_) < cb1 && q_ < np;                                                                     \
+        halo_issue_a<DUAL>(p, real_ ? smem + ((cb_) & 1) * a_bytes + q_ * 1024 : dummy, real_ ? off0[k_] : kOob,       \
+                           real_ ? off1[DUAL ? (k_) : 0] : kOob, (cb_) < cb1 ? (cb_) : 0);                             \
+    }
+    // W tile of K-tile index kt_ (= cb*9 + tap) into ring slot ws_; past the end of K: zeros
+#define MVLDM_HALO_W(kt_, ws_)                                                                                         \
+    {                                                                                                                  \
+        const bool real_ = (kt_) < cb1 * 9;                                                                            \
+        _Pragma("unroll") for (int it = 0; it < B_IT; ++it)                                                            \
+            halo_issue_w(p, wring + (ws_) * W_BYTES + (wave + NW * it) * 1024, real_ ? vb[it] : kOob, real_ ? (kt_) * 128 : 0); \
+    }
+
+    // prologue: the whole halo of block 0, W tiles 0..2
+#pragma unroll
+    for (int k = 0; k < KA; ++k) MVLDM_HALO_A(k, 0)
+    MVLDM_HALO_W(0, 0)
+    MVLDM_HALO_W(1, 1)
+    MVLDM_HALO_W(2, 2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment addressing of one tap: masked lanes read the zero row
+    const char* abase[TM];
+    int arow[TM];
+    const char* bt;
+#define MVLDM_HALO_ADDR(cb_, t_, ws_)                                                                                  \
+    {                                                                                                                  \
+        const int disp_ = lead + ((t_) / 3 - 1) * p.w_in + ((t_) % 3 - 1);   /* lane-uniform row displacement */        \
+        const char* as_ = smem + ((cb_) & 1) * a_bytes;                                                                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                               \
+            const bool ok_ = (mask[i] >> (t_)) & 1u;                                                                   \
+            abase[i] = ok_ ? as_ : zrow;                                                                               \
+            arow[i] = ok_ ? rloc[i] + disp_ : 0;                                                                       \
+        }                                                                                                              \
+        bt = wring + (ws_) * W_BYTES;                                                                                  \
+    }
+#define MVLDM_HALO_LOAD(f_, kk_)                                                                                       \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) f_.a[i] = M_::load(abase[i], arow[i], kk_, hi);                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) f_.b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk_, hi); \
+    }
+#define MVLDM_HALO_MMA(f_)                \
+    __builtin_amdgcn_sched_barrier(0);    \
+    bl_mma<T, TM, TN>(f_, acc);           \
+    __builtin_amdgcn_sched_barrier(0);
+
+    int wslot = 0, kt = 0;
+    BlFrags<T, TM, TN> f0, f1;
+    MVLDM_HALO_ADDR(0, 0, 0)
+    MVLDM_HALO_LOAD(f0, 0)
+    for (int cb = 0; cb < cb1; ++cb) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++kt) {
+            MVLDM_HALO_LOAD(f1, 1)
+            MVLDM_HALO_MMA(f0)
+            MVLDM_HALO_LOAD(f0, 2)
+            MVLDM_HALO_MMA(f1)
+            MVLDM_HALO_LOAD(f1, 3)
+            MVLDM_HALO_MMA(f0)
+            // W tile kt+1 must have landed; behind it at most {halo piece, W tile kt+2, halo piece} = 4 loads are in flight
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            MVLDM_HALO_W(kt + 3, wslot)
+            if (t < KA) { MVLDM_HALO_A(t, cb + 1) }
+            else { MVLDM_HALO_A(0, cb1) }                                     // (keeps the per-step load count uniform)
+            wslot = wslot == 2 ? 0 : wslot + 1;
+            // first fragments of the next K-tile under the last MFMAs of this one (past the end: harmless reads)
+            if (t < 8) { MVLDM_HALO_ADDR(cb, t + 1, wslot) }
+            else { MVLDM_HALO_ADDR(cb + 1, 0, wslot) }
+            MVLDM_HALO_LOAD(f0, 0)
+            MVLDM_HALO_MMA(f1)
+        }
+    }
+#undef MVLDM_HALO_ADDR
+#undef MVLDM_HALO_LOAD
+#undef MVLDM_HALO_MMA
+#undef MVLDM_HALO_A
+#undef MVLDM_HALO_W
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
+}
+
 // split-K: sum the fp32 partial slabs and run the same epilogue (deterministic, no atomics)
 template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmParams p) {
     const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
@@ -803,9 +989,10 @@ static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64
                                  {256, 128, 512},    // tile 7: 8 waves of 64x64 -- half the L2->LDS bytes per flop of tile 2
                                  {128, 256, 512},    // tile 8
                                  {256, 256, 512},    // tile 9: 8 waves of 64x128, 2-deep ring (128 KB): 128 flop per L2->LDS byte
-                                 {256, 320, 512}};   // tile 10: 8 waves of 64x160 -- every channel count of this UNet is a
+                                 {256, 320, 512},    // tile 10: 8 waves of 64x160 -- every channel count of this UNet is a
                                                      // multiple of 320 (no N padding); 142 flop per L2->LDS byte
-constexpr int kNumTiles = 10;
+                                 {256, 128, 512}};   // tile 11: 256x128 with the LDS-resident pixel halo (3x3 stride-1 convs)
+constexpr int kNumTiles = 11;
 
 // tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
 // target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
@@ -879,6 +1066,22 @@ template <typename T, int BM, int BN, int WM, int WN> static int launch_tile(con
     return launch_sync<T, BM, BN, WM, WN>(p, s);
 }
 
+static inline int halo_rows_for(int w_in) { return (256 + 2 * (w_in + 1) + 7) / 8 * 8; }
+template <typename T> static int launch_halo(const IgemmParams& p, hipStream_t s) {
+    const int hr = halo_rows_for(p.w_in);
+    const int smem = 2 * hr * 128 + 3 * 128 * 128 + 128 + 1024;
+    const int blocks = 8 * p.sub_m * p.sub_n;
+    static bool done0 = false, done1 = false;
+    if (p.c1 > 0) {
+        if (!done1) { MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done1 = true; }
+        hipLaunchKernelGGL((igemm_halo_kernel<T, true>), dim3(blocks), dim3(512), smem, s, p, hr);
+    } else {
+        if (!done0) { MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done0 = true; }
+        hipLaunchKernelGGL((igemm_halo_kernel<T, false>), dim3(blocks), dim3(512), smem, s, p, hr);
+    }
+    return check_launch();
+}
+
 template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStream_t s) {
     switch (tile) {
         case 1: return launch_tile<T, 128, 128, 2, 2>(p, s);
@@ -911,6 +1114,11 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
                 if (p.use_bl) return launch_bl_any<T, 256, 320, 4, 2>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 10 needs the 16-bit block-major path");
+        case 11:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_halo<T>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 11 needs the 16-bit block-major path");
         default: return set_error(MVLDM_ERR_ARG, "igemm: bad tile %d", tile);
     }
 }
@@ -1017,6 +1225,10 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     // LDS-staged epilogue: 16-byte rows need 8-column alignment of the 16-bit output (or a split-K slab)
     p.stage_epi = p.use_bl && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
     if (tile >= 9 && (!p.stage_epi || (tile == 10 && d.epilogue == MVLDM_EPI_GEGLU))) tile = 7;   // no per-element epilogue there; odd TN cannot pair GEGLU columns
+    if (tile == 11 && !(p.use_bl && p.stage_epi && p.splitk == 1 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
+                        d.h_out == d.h_in && d.w_out == d.w_in && halo_rows_for(d.w_in) <= 384 &&
+                        2 * halo_rows_for(d.w_in) * 128 + 3 * 128 * 128 + 1152 <= 160 * 1024))
+        tile = 7;   // the halo kernel only does 3x3 / stride 1 / pad 1 on images up to 63 pixels wide, one K pass
     if (p.use_bl && d.upsample && tile != 7) tile = 2;
     if (p.use_bl && !d.upsample) {
         // the lean loop addresses every tap relative to the centre tap: it must lie inside the image

@@ -106,7 +106,7 @@ def test_conv_tiles_and_splitk(ops, dtype):
     ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
     pw = ops.pack_weight(wt.cuda(), dtype)
     xg = nhwc(x, dtype)
-    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)
+    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
     for tile in tiles:
         for sk in (1, 2, 5):
             y = ops.conv2d(xg, pw, b.cuda(), tile=tile, splitk=sk)
@@ -335,3 +335,28 @@ def test_ddim_cfg_step_bit_exact(ops):
         ref_nocfg = s.step(eps[cond.long()], t, x).prev_sample
         got = ops.ddim_cfg_step(eps.cuda(), x.cuda(), cond.cuda(), None, 3.0, coef.cuda(), sp, None)
         assert torch.equal(got.cpu(), ref_nocfg)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,c0,c1,cout,h,w", [(3, 64, 0, 96, 5, 7), (2, 128, 64, 128, 16, 16), (5, 320, 0, 320, 32, 32), (9, 640, 640, 640, 8, 8),
+                                              (40, 128, 0, 64, 4, 4), (1, 64, 0, 64, 40, 44)],
+                         ids=["odd_5x7", "dual_16x16", "L0_32x32", "dual_8x8", "many_4x4", "wide_44"])
+def test_conv3x3_halo_tile(ops, dtype, n, c0, c1, cout, h, w):
+    """tile 11: the LDS-resident pixel-halo kernel (all 9 taps served from one halo tile per channel block): image
+    borders, tiles spanning several images, ragged last tile, two sources, epilogues"""
+    x = rnd((n, c0, h, w), 31, dtype)
+    x2 = rnd((n, c1, h, w), 32, dtype) if c1 else None
+    wt = rnd((cout, c0 + c1, 3, 3), 33, dtype, 1 / math.sqrt((c0 + c1) * 9))
+    b = torch.randn(cout, generator=G(34)) * 0.1
+    rb = torch.randn(n, cout, generator=G(35))
+    res = rnd((n, cout, h, w), 36, dtype)
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=1)
+    pw = ops.pack_weight(wt.cuda(), dtype, c_split=c0 if c1 else None)
+    xg, x2g = nhwc(x, dtype), (None if x2 is None else nhwc(x2, dtype))
+    y = ops.conv2d(xg, pw, b.cuda(), x2=x2g, tile=11, splitk=1)
+    close(nchw(y), ref, dtype, "halo")
+    y7 = ops.conv2d(xg, pw, b.cuda(), x2=x2g, tile=7, splitk=1)
+    assert torch.equal(y, y7)                     # same K order as the streaming kernel: bit-identical
+    y = ops.conv2d(xg, pw, b.cuda(), x2=x2g, row_bias=rb.cuda(), residual=nhwc(res, dtype), tile=11, splitk=1)
+    close(nchw(y), ref + rb.double()[:, :, None, None] + res.double(), dtype, "halo temb+residual")

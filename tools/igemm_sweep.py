@@ -51,7 +51,7 @@ for name, ni, h, c0, c1, co, k, geglu in SHAPES:
     flops = 2.0 * ni * h * h * co * (c0 + c1) * k * k
     best = None
     combos = []
-    for tile in (1, 2, 3, 6, 7, 8, 9, 10):
+    for tile in (1, 2, 3, 6, 7, 8, 9, 10, 11):
         combos.append((tile, 0, 1, 0, 0))   # lean buffer-load loop (default for block-major K), ring depth st
     for tile in (2, 3):
         combos.append((tile, 0, 1, 0, 1))            # register-prefetch loop (bit 12)
