@@ -143,6 +143,8 @@ class Builder:
         es = x.element_size()
         nbytes = (pw.n_out * k_real + n * h * w * (c0 + c1)) * es + m * n_dst * out.element_size() \
             + (m * n_dst * es if residual is not None else 0)
+        if self.record:
+            self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = (x, x2)
         self._emit(op, name, 2.0 * m * pw.n_out * k_real, nbytes, (x, x2, pw.data, bias, row_bias, residual, out))
         return out
 
@@ -268,7 +270,7 @@ class Builder:
         if autotune is None:
             autotune = os.environ.get("MVLDM_AUTOTUNE", "1") != "0"
         if autotune and torch.device(self.device).type == "cuda":
-            autotune_igemm(self.ops)
+            autotune_igemm(self.ops, srcs=self.__dict__.get("_tune_srcs"))
         return Plan(self.ops, self.meta, self.keep, self.device)
 
 
@@ -288,13 +290,22 @@ def _igemm_signature(d) -> tuple:
             bool(d.bias), d.splitk, d.workspace_bytes)
 
 
-def autotune_igemm(ops, min_rows: int = 2048, iters: int = 3) -> int:
+def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
     """set `desc.tile` of every auto-tiled 16-bit block-major igemm op with >= `min_rows` output rows to the
-    fastest candidate; returns the number of distinct problems timed"""
+    fastest candidate; returns the number of distinct problems timed.  `srcs`: {op index: (x, x2)} source tensors of
+    the recorded convs -- they hold scratch at this point and are filled with N(0,1) first: on zeros / NaNs the
+    chip draws less power and clocks higher, which ranks the candidates differently from real data."""
     lib = L.load()
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     timed = 0
+    if srcs:
+        seen = set()
+        for pair in srcs.values():
+            for t in pair:
+                if t is not None and t.is_floating_point() and t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    t.normal_()
     for op in ops:
         if op.kind != L.OP_IGEMM:
             continue
