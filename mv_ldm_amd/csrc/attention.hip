@@ -448,9 +448,10 @@ template <typename T, int DP> static int launch_attn(AttnParams p, int n_seg, in
 int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,
                   int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len, float scale, int dtype,
                   hipStream_t s) {
-    MVLDM_REQUIRE(q && k && v && out && seg, "attention: null pointer");
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(head_dim > 0 && head_dim % epc == 0, "attention: head_dim %d must be a multiple of %d", head_dim, epc);
+    if (n_seg == 0 || max_q_len == 0) return MVLDM_OK;   // empty: buffers may be null
+    MVLDM_REQUIRE(q && k && v && out && seg, "attention: null pointer");
     MVLDM_REQUIRE(ld_q % epc == 0 && ld_k % epc == 0 && ld_v % epc == 0 && ld_o % 4 == 0, "attention: row strides must keep 16-byte alignment");
     if (n_seg == 0 || max_q_len == 0) return MVLDM_OK;
     AttnParams p{q, k, v, out, seg, ld_q, ld_k, ld_v, ld_o, heads, head_dim, scale * 1.4426950408889634f, 0, 0};

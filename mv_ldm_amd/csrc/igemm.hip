@@ -1264,6 +1264,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
 int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
     IgemmParams p;
     int tile = 0;
+    if (d.n_img == 0 || d.h_out == 0 || d.w_out == 0) return MVLDM_OK;   // empty batch: nothing to do (its buffers may be null)
     int rc = fill_params(d, p, tile);
     if (rc) return rc;
     if (p.M == 0) return MVLDM_OK;

@@ -312,6 +312,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, const float* beta, int n_img, int hw, int c0,
                   int c1, int groups, float eps, int silu, int dtype, void* stats_ws, hipStream_t s) {
+    MVLDM_REQUIRE(groups > 0 && groups <= 64 && (c0 + c1) % groups == 0, "groupnorm: c=%d groups=%d", c0 + c1, groups);
+    if (n_img == 0 || hw == 0) return MVLDM_OK;   // empty: buffers may be null
     MVLDM_REQUIRE(x && y && gamma && beta && stats_ws, "groupnorm: null pointer");
     MVLDM_REQUIRE((c1 == 0) == (x1 == nullptr), "groupnorm: x1/c1 mismatch");
     const int c = c0 + c1;
@@ -359,6 +361,7 @@ int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, co
 
 int layernorm_run(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps, int dtype,
                   hipStream_t s) {
+    if (rows == 0) return MVLDM_OK;   // empty: buffers may be null
     MVLDM_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(c % epc == 0, "layernorm: c=%d must be a multiple of %d", c, epc);

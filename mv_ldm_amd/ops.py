@@ -11,6 +11,8 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Optional
 
+import math
+
 import torch
 
 from . import _lib as L
@@ -160,9 +162,9 @@ def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool,
     assert x.is_cuda and x.is_contiguous() and (x2 is None or x2.is_contiguous())
     n, c0 = x.shape[0], x.shape[-1]
     c1 = 0 if x2 is None else x2.shape[-1]
-    hw = x.numel() // (n * c0)
+    hw = math.prod(x.shape[1:-1])
     y = torch.empty(*x.shape[:-1], c0 + c1, dtype=x.dtype, device=x.device)
-    ws = workspace(n * L.GN_MAX_CHUNKS * groups * 2 * 8, x.device, "gn")
+    ws = workspace(max(n, 1) * L.GN_MAX_CHUNKS * groups * 2 * 8, x.device, "gn")
     L.check(L.load().mvldm_groupnorm_fwd(x.data_ptr(), ptr(x2), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, hw, c0, c1,
                                          groups, eps, int(silu), dt(x), ws.data_ptr(), stream()))
     return y

@@ -360,3 +360,29 @@ def test_conv3x3_halo_tile(ops, dtype, n, c0, c1, cout, h, w):
     assert torch.equal(y, y7)                     # same K order as the streaming kernel: bit-identical
     y = ops.conv2d(xg, pw, b.cuda(), x2=x2g, row_bias=rb.cuda(), residual=nhwc(res, dtype), tile=11, splitk=1)
     close(nchw(y), ref + rb.double()[:, :, None, None] + res.double(), dtype, "halo temb+residual")
+
+
+def test_empty_and_degenerate_inputs(ops):
+    """zero images / rows / segments are no-ops (no launch, no error); one-pixel images and one-token sequences work;
+    bad arguments are refused by the C side (negative return code -> exception), never silently computed elsewhere"""
+    from mv_ldm_amd._lib import MvldmError
+    dt_ = torch.bfloat16
+    w = torch.randn(64, 64, 3, 3, generator=G(41))
+    pw = ops.pack_weight(w.cuda(), dt_)
+    y = ops.conv2d(torch.empty(0, 8, 8, 64, dtype=dt_, device="cuda"), pw)
+    assert y.shape == (0, 8, 8, 64)
+    x1 = rnd((2, 64, 1, 1), 42, dt_)                       # 1x1 images: only the centre tap is inside
+    y = ops.conv2d(nhwc(x1, dt_), pw)
+    close(nchw(y), F.conv2d(x1.double(), w.to(dt_).double(), padding=1), dt_, "1x1 image")
+    g, b = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    assert ops.groupnorm(torch.empty(0, 4, 4, 64, dtype=dt_, device="cuda"), g, b, 32, 1e-5, True).shape == (0, 4, 4, 64)
+    assert ops.layernorm(torch.empty(0, 64, dtype=dt_, device="cuda"), g, b).shape == (0, 64)
+    q = rnd((5, 64), 43, dt_).to(dt_).cuda()
+    o = ops.attention(q, q, q, 1, 64, ops.make_segments([1, 1, 3]), 3)      # one-token sequences: softmax over one key = V
+    assert torch.isfinite(o.float()).all() and float((o[:2].float() - q[:2].float()).abs().max()) == 0.0
+    o = ops.attention(q[:0], q[:0], q[:0], 1, 64, ops.make_segments([]), 0)
+    assert o.shape == (0, 64)
+    with pytest.raises(MvldmError):
+        ops.attention(q, q, q, 1, 63, ops.make_segments([5]), 5)             # head_dim not a multiple of 8
+    with pytest.raises(MvldmError):
+        ops.groupnorm(torch.empty(1, 2, 2, 64, dtype=dt_, device="cuda"), g, b, 48, 1e-5, False)   # 64 % 48 != 0
