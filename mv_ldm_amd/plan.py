@@ -56,6 +56,7 @@ class Builder:
         t = torch.empty(*shape, dtype=dtype, device=self.device)
         if self.record:
             self.keep.append(t)
+            self.__dict__.setdefault("_own_ptrs", set()).add(t.data_ptr())
         return t
 
     def free(self, t: Optional[torch.Tensor]):
@@ -144,7 +145,10 @@ class Builder:
         nbytes = (pw.n_out * k_real + n * h * w * (c0 + c1)) * es + m * n_dst * out.element_size() \
             + (m * n_dst * es if residual is not None else 0)
         if self.record:
-            self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = (x, x2)
+            # (only temporaries of this builder's own pool may be filled with timing data: a caller's tensor is left alone)
+            own = self.__dict__.get("_own_ptrs", ())
+            self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = tuple(t if (t is not None and t.data_ptr() in own) else None
+                                                                              for t in (x, x2))
         self._emit(op, name, 2.0 * m * pw.n_out * k_real, nbytes, (x, x2, pw.data, bias, row_bias, residual, out))
         return out
 
@@ -300,12 +304,15 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     timed = 0
     if srcs:
-        seen = set()
+        seen, gen = set(), None
         for pair in srcs.values():
             for t in pair:
                 if t is not None and t.is_floating_point() and t.data_ptr() not in seen:
                     seen.add(t.data_ptr())
-                    t.normal_()
+                    if gen is None:     # a private generator: the caller's CUDA RNG stream must not move
+                        gen = torch.Generator(device=t.device)
+                        gen.manual_seed(0x5EED)
+                    t.normal_(generator=gen)
     for op in ops:
         if op.kind != L.OP_IGEMM:
             continue
