@@ -66,7 +66,10 @@ typedef struct mvldm_igemm_desc {
     float* workspace;      /* split-K scratch, >= splitk*m*n_pad floats when splitk > 1 */
     int32_t c0, c1;
     int32_t n_img, h_in, w_in, h_out, w_out;
-    int32_t ksize, stride, pad, upsample;
+    int32_t ksize, stride, pad, upsample;   /* ksize 1 | 3 (2 with upsample >= 2).  upsample: 0 none; 1 nearest-2x source
+                                               indexing in front of a 3x3 conv (diffusers Upsample2D); 2 + 2*py + px = sub-pixel
+                                               phase (py, px) of the same conv decomposed into four 2x2 convs on the LOW-resolution
+                                               image (h_out = h_in, w_out = w_in; rows are scattered to (2i+py, 2j+px) of dst) */
     int32_t n_out, n_pad, k_pad;
     int32_t row_bias_ld;
     int32_t epilogue;   /* MVLDM_EPI_* */

@@ -36,6 +36,8 @@ struct IgemmParams {
     int px, sub_m, sub_n, m_fast;  // XCD-aware 2-D tile partition
     int rb_vec;                    // row_bias rows are 16-byte addressable (base and leading dimension)
     int bias_vec;                  // bias is 16-byte aligned
+    int ty0, tx0, cy, cx;          // tap origin relative to (oy*stride, ox*stride), and the always-inside reference tap
+    int scatter, ph_y, ph_x;       // sub-pixel phase of a decomposed nearest-2x upsampling conv: output row m -> (2i+py, 2j+px)
     int fake;                      // EXPERIMENT knob (MVLDM_IGEMM_FAKE): bit 2 = no global stores / residual loads, bit 3 = no epilogue
     unsigned src0_bytes, src1_bytes, w_bytes;   // buffer-descriptor extents (lean 16-bit loop)
     int use_bl, stage_epi;
@@ -282,7 +284,13 @@ __device__ __forceinline__ void epi_rows(const IgemmParams& p, const float* st, 
             Chunk<T> oc;
 #pragma unroll
             for (int e = 0; e < 8; ++e) oc.set(e, v[e]);
-            store_chunk<T>(reinterpret_cast<T*>(p.dst) + (size_t)m * p.dst_ld + n0, oc);
+            size_t drow = (size_t)m;
+            if (p.scatter) {   // sub-pixel phase: low-resolution pixel (i, j) of image `img` -> (2i+py, 2j+px) of the 2x output
+                const int img = m / p.hw_out, rem = m - img * p.hw_out;
+                const int i = rem / p.w_out, j = rem - i * p.w_out;
+                drow = ((size_t)img * (2 * p.h_out) + 2 * i + p.ph_y) * (size_t)(2 * p.w_out) + 2 * j + p.ph_x;
+            }
+            store_chunk<T>(reinterpret_cast<T*>(p.dst) + drow * p.dst_ld + n0, oc);
         }
     }
 }
@@ -482,8 +490,8 @@ template <typename T, int BM, int BN, int NW, int KS, bool DUAL, int A_IT, int B
 __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base, int wave, int cb,
                                          const BlAddr<KS * KS, A_IT, DUAL, UPS>& ad, const unsigned (&vb)[B_IT]) {
     constexpr int BK = 64, TAPS = KS * KS;
-    const int lead = (!UPS && KS == 3) ? p.w_in + 1 : 0;                                        // pixels
-    const int disp = UPS ? 0 : (t / KS - KS / 2) * p.w_in + (t % KS - KS / 2) + lead;           // >= 0
+    const int lead = (!UPS && KS > 1) ? p.w_in + 1 : 0;                                         // pixels
+    const int disp = UPS ? 0 : (t / KS - p.cy) * p.w_in + (t % KS - p.cx) + lead;               // >= 0
     const unsigned lead0 = (unsigned)lead * (unsigned)p.c0 * 2u, lead1 = (unsigned)lead * (unsigned)p.c1 * 2u;
     const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.src0)) - lead0, 0, p.src0_bytes + lead0, 0x00020000);
@@ -607,12 +615,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
             }
         } else {
             // centre tap (inside the image for every live row: checked on the host)
-            const int yc = oy * p.stride - p.pad + KS / 2, xc = ox * p.stride - p.pad + KS / 2;
+            const int yc = oy * p.stride + p.ty0 + p.cy, xc = ox * p.stride + p.tx0 + p.cx;
             const unsigned pix = (unsigned)(img * p.h_in + yc) * (unsigned)p.w_in + (unsigned)xc;
             unsigned msk = 0;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                const int iy = yc + t / KS - KS / 2, ix = xc + t % KS - KS / 2;
+                const int iy = yc + t / KS - p.cy, ix = xc + t % KS - p.cx;
                 msk |= (live && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) ? (1u << t) : 0u;
             }
             ad.a0[0][it] = (pix * (unsigned)p.c0 + chunk) * 2u;
@@ -695,6 +703,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
             int slot_c = 0;
             for (int cb = cb0; cb < cb1; ++cb) {
                 MVLDM_BL_STEP_SIMPLE(0)
+                if constexpr (TAPS == 4) { MVLDM_BL_STEP_SIMPLE(1) MVLDM_BL_STEP_SIMPLE(2) MVLDM_BL_STEP_SIMPLE(3) }
                 if constexpr (TAPS == 9) {
                     MVLDM_BL_STEP_SIMPLE(1) MVLDM_BL_STEP_SIMPLE(2) MVLDM_BL_STEP_SIMPLE(3) MVLDM_BL_STEP_SIMPLE(4)
                     MVLDM_BL_STEP_SIMPLE(5) MVLDM_BL_STEP_SIMPLE(6) MVLDM_BL_STEP_SIMPLE(7) MVLDM_BL_STEP_SIMPLE(8)
@@ -718,6 +727,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         MVLDM_BL_LOAD(f0, 0, 0);
         for (int cb = cb0; cb < cb1; ++cb) {
             MVLDM_BL_STEP(0)
+            if constexpr (TAPS == 4) { MVLDM_BL_STEP(1) MVLDM_BL_STEP(2) MVLDM_BL_STEP(3) }
             if constexpr (TAPS == 9) {
                 MVLDM_BL_STEP(1) MVLDM_BL_STEP(2) MVLDM_BL_STEP(3) MVLDM_BL_STEP(4)
                 MVLDM_BL_STEP(5) MVLDM_BL_STEP(6) MVLDM_BL_STEP(7) MVLDM_BL_STEP(8)
@@ -1053,6 +1063,12 @@ static int launch_bl(const IgemmParams& p, hipStream_t s) {
 }
 template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(const IgemmParams& p, hipStream_t s) {
     const bool dual = p.c1 > 0;
+    if (p.ksize == 2) {   // the four 2x2 phases of a decomposed nearest-2x upsampling conv: tiles 2, 7 and 10 only
+        if constexpr ((BM == 128 && BN == 64) || (BM == 256 && BN == 128) || (BM == 256 && BN == 320))
+            return launch_bl<T, BM, BN, WM, WN, 2, false>(p, s);
+        else
+            return set_error(MVLDM_ERR_ARG, "igemm: 2x2 phase conv needs tile 2, 7 or 10");
+    }
     if (p.ksize == 3) return dual ? launch_bl<T, BM, BN, WM, WN, 3, true>(p, s) : launch_bl<T, BM, BN, WM, WN, 3, false>(p, s);
     return dual ? launch_bl<T, BM, BN, WM, WN, 1, true>(p, s) : launch_bl<T, BM, BN, WM, WN, 1, false>(p, s);
 }
@@ -1138,14 +1154,14 @@ static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& ti
         // only ~1 workgroup per CU: needs whole rounds of 256 workgroups (sweep5: +14..33 % on the 32x32-level
         // convs / Linears at 32 scenes, a loss below ~2 rounds)
         const bool can10 = d.act_dtype != MVLDM_F32 && d.k_order == 1 && d.dst_dtype != MVLDM_F32 && d.n_pad % 320 == 0 &&
-                           d.epilogue != MVLDM_EPI_GEGLU && !d.upsample && d.n_out % 8 == 0 && (d.dst_ld <= 0 || d.dst_ld % 8 == 0);
+                           d.epilogue != MVLDM_EPI_GEGLU && d.upsample != 1 && d.n_out % 8 == 0 && (d.dst_ld <= 0 || d.dst_ld % 8 == 0);
         const int wgs10 = cdiv(M, 256) * (d.n_pad / 320);
         const double eff10 = (double)wgs10 / (256.0 * cdiv(wgs10, 256));
         // (Linears keep winning down to 2 ragged rounds: 908 vs 850 TFLOP/s at 576 workgroups; 3x3 convs do not)
         if (can10 && (wgs10 >= 1024 || (wgs10 >= 512 && (eff10 >= 0.9 || d.ksize == 1)))) tile = 10;
         else if (M <= 32) tile = 5;
         else if (M <= 64) tile = 4;
-        else if (d.ksize == 3) tile = cdiv(M, 256) * cdiv(d.n_pad, 128) >= 300 ? 7 : 2;
+        else if (d.ksize >= 2) tile = cdiv(M, 256) * cdiv(d.n_pad, 128) >= 300 ? 7 : 2;
         else if (d.n_pad >= 768 && d.act_dtype != MVLDM_F32 && d.k_order == 1 && d.dst_dtype != MVLDM_F32 &&
                  cdiv(M, 256) * cdiv(d.n_pad, 256) >= 1024)
             tile = 9;   // wide Linear (QKV, GEGLU) with >= 4 rounds of workgroups: 256x256 measured +10-15 % over
@@ -1168,7 +1184,14 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     const int epc = d.act_dtype == MVLDM_F32 ? 4 : 8;
     const int bk = d.act_dtype == MVLDM_F32 ? 32 : 64;
     MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
-    MVLDM_REQUIRE(d.ksize == 1 || d.ksize == 3, "igemm: ksize %d", d.ksize);
+    // upsample: 0 none, 1 nearest-2x before a 3x3 conv (gather form), 2..5 = sub-pixel phase (py, px) = ((u-2)>>1, (u-2)&1) of the
+    // same conv decomposed into four 2x2 convs on the low-resolution image (weights pre-summed by the caller)
+    const bool phase = d.upsample >= 2;
+    MVLDM_REQUIRE(d.upsample >= 0 && d.upsample <= 5, "igemm: upsample %d", d.upsample);
+    MVLDM_REQUIRE(phase ? (d.ksize == 2 && d.stride == 1 && d.h_out == d.h_in && d.w_out == d.w_in && !d.src1 && !d.residual &&
+                           !d.row_bias && d.act_dtype != MVLDM_F32 && d.dst_dtype == d.act_dtype && d.k_order == 1)
+                        : (d.ksize == 1 || d.ksize == 3),
+                  "igemm: ksize %d / upsample %d", d.ksize, d.upsample);
     MVLDM_REQUIRE(d.stride == 1 || d.stride == 2, "igemm: stride %d", d.stride);
     MVLDM_REQUIRE(d.c0 % epc == 0 && d.c1 % epc == 0 && d.c0 > 0, "igemm: channels (%d,%d) must be multiples of %d", d.c0, d.c1, epc);
     MVLDM_REQUIRE((d.c1 == 0) == (d.src1 == nullptr), "igemm: src1/c1 mismatch");
@@ -1182,7 +1205,12 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.c0 = d.c0; p.c1 = d.c1; p.ctot = d.c0 + d.c1;
     p.n_img = d.n_img; p.h_in = d.h_in; p.w_in = d.w_in; p.h_out = d.h_out; p.w_out = d.w_out;
     p.hw_out = d.h_out * d.w_out;
-    p.ksize = d.ksize; p.stride = d.stride; p.pad = d.pad; p.upsample = d.upsample; p.taps = d.ksize * d.ksize;
+    p.ksize = d.ksize; p.stride = d.stride; p.pad = d.pad; p.upsample = phase ? 0 : d.upsample; p.taps = d.ksize * d.ksize;
+    p.scatter = phase; p.ph_y = phase ? (d.upsample - 2) >> 1 : 0; p.ph_x = phase ? (d.upsample - 2) & 1 : 0;
+    // tap t reads input pixel (oy*stride + ty0 + t/ks, ox*stride + tx0 + t%ks); (cy, cx) is a tap offset that is inside the image
+    // for every output pixel: the centre of a padded 3x3 / the pixel itself for a 2x2 phase (whose taps start at py-1, px-1)
+    p.ty0 = phase ? p.ph_y - 1 : -d.pad; p.tx0 = phase ? p.ph_x - 1 : -d.pad;
+    p.cy = phase ? 1 - p.ph_y : d.ksize / 2; p.cx = phase ? 1 - p.ph_x : d.ksize / 2;
     p.M = d.n_img * p.hw_out; p.n_out = d.n_out; p.n_pad = d.n_pad; p.k_pad = d.k_pad;
     p.n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
     p.rb_vec = d.row_bias && ((uintptr_t)d.row_bias % 16 == 0) && d.row_bias_ld % 4 == 0;
@@ -1198,6 +1226,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     int splitk = d.splitk;
     MVLDM_REQUIRE(tile >= 0 && tile <= kNumTiles && splitk >= 0, "igemm: tile/splitk");
     choose_config(d, p.M, p.k_tiles, tile, splitk, d.workspace_bytes);
+    if (phase) splitk = 1;   // the four phases interleave in the output: no split-K slabs for them
     if (splitk > 1)
         MVLDM_REQUIRE(d.workspace && (size_t)splitk * p.M * d.n_pad * sizeof(float) <= d.workspace_bytes,
                       "igemm: split-K workspace too small");
@@ -1229,11 +1258,16 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
                         d.h_out == d.h_in && d.w_out == d.w_in && halo_rows_for(d.w_in) <= 384 &&
                         2 * halo_rows_for(d.w_in) * 128 + 3 * 128 * 128 + 1152 <= 160 * 1024))
         tile = 7;   // the halo kernel only does 3x3 / stride 1 / pad 1 on images up to 63 pixels wide, one K pass
-    if (p.use_bl && d.upsample && tile != 7) tile = 2;
-    if (p.use_bl && !d.upsample) {
+    if (phase) {
+        MVLDM_REQUIRE(p.use_bl && p.splitk == 1 && p.stage_epi, "igemm: 2x2 phase conv needs the lean 16-bit loop, one K pass, 8-aligned 16-bit output");
+        if (tile != 7 && tile != 10) tile = 2;
+    }
+    if (p.use_bl && d.upsample == 1 && tile != 7) tile = 2;
+    if (p.use_bl && d.upsample != 1) {
         // the lean loop addresses every tap relative to the centre tap: it must lie inside the image
-        const int hc = (d.h_out - 1) * d.stride - d.pad + d.ksize / 2, wc = (d.w_out - 1) * d.stride - d.pad + d.ksize / 2;
-        MVLDM_REQUIRE(d.pad <= d.ksize / 2 && hc < d.h_in && wc < d.w_in, "igemm: conv geometry (pad %d, stride %d) not supported", d.pad, d.stride);
+        const int hc = (d.h_out - 1) * d.stride + p.ty0 + p.cy, wc = (d.w_out - 1) * d.stride + p.tx0 + p.cx;
+        MVLDM_REQUIRE(p.ty0 + p.cy >= 0 && p.tx0 + p.cx >= 0 && hc < d.h_in && wc < d.w_in,
+                      "igemm: conv geometry (pad %d, stride %d) not supported", d.pad, d.stride);
     }
     p.tiles_m = cdiv(p.M, kTiles[tile].bm);
     p.tiles_n = cdiv(d.n_pad, kTiles[tile].bn);

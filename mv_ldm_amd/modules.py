@@ -20,6 +20,7 @@ a parameter changes.
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import List, Optional, Sequence
 
@@ -402,7 +403,14 @@ class Upsample2D(nn.Module):
         self.conv = Conv2d(channels, out_channels or channels, 3, padding=1)
 
     def emit(self, b: Builder, x):
-        return self.conv.emit(b, x, upsample=True, name="upsample")  # nearest x2 folded into the gather
+        c = x.shape[-1]
+        if (b.dtype != torch.float32 and c % ops.block_k(b.dtype) == 0 and self.conv.out_channels % 8 == 0
+                and os.environ.get("MVLDM_UPSAMPLE_GATHER", "0") != "1"):     # (A/B knob: 1 = the 9-tap gather form)
+            # nearest x2 + 3x3 = four 2x2 convs on the low-resolution image (4/9 of the multiply-adds)
+            pws = self.conv._cache(("wphase", b.dtype), [self.conv.weight],
+                                   lambda: [ops.pack_weight(w, b.dtype) for w in ops.upsample_phase_weights(self.conv.weight)])
+            return b.conv_upsample_phases(x, pws, self.conv._f32("bias"), name="upsample")
+        return self.conv.emit(b, x, upsample=True, name="upsample")  # f32 / odd channel counts: nearest x2 folded into the gather
 
     def forward(self, x):
         b = eager_builder(x)

@@ -105,7 +105,7 @@ def igemm_desc(src0, src1, pw: PackedWeight, dst, *, n_img, h_in, w_in, h_out, w
     d.bias, d.row_bias, d.residual, d.dst = ptr(bias), ptr(row_bias), ptr(residual), ptr(dst)
     d.c0, d.c1 = c0, c1
     d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n_img, h_in, w_in, h_out, w_out
-    d.ksize, d.stride, d.upsample = pw.ksize, stride, int(upsample)
+    d.ksize, d.stride, d.upsample = pw.ksize, stride, int(upsample)      # 0/1, or 2 + phase (see upsample_phase_weights)
     d.pad = (pw.ksize // 2) if pad is None else pad
     d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
     d.row_bias_ld = 0 if row_bias is None else row_bias.stride(0)
@@ -144,6 +144,37 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, bias=None, *, x2=None, stride=1, p
                    upsample=upsample, bias=bias, row_bias=row_bias, residual=residual, epilogue=epilogue,
                    out_scale=out_scale, ws=scratch, splitk=splitk, tile=tile)
     L.check(L.load().mvldm_igemm_fwd(C.byref(d), stream()))
+    return out
+
+
+def upsample_phase_weights(w: torch.Tensor) -> list:
+    """nearest-2x upsampling followed by a 3x3 / pad-1 conv equals four 2x2 convs on the LOW-resolution image, one per
+    output parity (py, px): output (2i+py, 2j+px) reads input rows {i-1+py, i+py} and columns {j-1+px, j+px} with the 3x3
+    taps that land on the same source pixel pre-summed (rows: py=0 -> [w0, w1+w2], py=1 -> [w0+w1, w2]; columns alike).
+    4/9 of the multiply-adds, exact up to the rounding of the summed weights.  Returns the fp32 `[n, c, 2, 2]` weights of
+    phases 0..3 (phase = 2*py + px)."""
+    assert w.ndim == 4 and w.shape[2:] == (3, 3)
+    w = w.detach().to(torch.float32)
+    rows = {0: (w[:, :, 0], w[:, :, 1] + w[:, :, 2]), 1: (w[:, :, 0] + w[:, :, 1], w[:, :, 2])}     # [n, c, 3(kx)] each
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = []
+            for r in rows[py]:
+                cols = (r[:, :, 0], r[:, :, 1] + r[:, :, 2]) if px == 0 else (r[:, :, 0] + r[:, :, 1], r[:, :, 2])
+                taps.append(torch.stack(cols, dim=-1))
+            out.append(torch.stack(taps, dim=-2).contiguous())       # [n, c, 2(ky), 2(kx)]
+    return out
+
+
+def conv2d_upsample_phases(x: torch.Tensor, pws, bias=None, tile=0) -> torch.Tensor:
+    """x NHWC `[n, h, w, c]` (16-bit); `pws`: the 4 packed phase weights -> NHWC `[n, 2h, 2w, n_out]`"""
+    n, h, w, _ = x.shape
+    out = torch.empty(n, 2 * h, 2 * w, pws[0].n_out, dtype=x.dtype, device=x.device)
+    for phase, pw in enumerate(pws):
+        d = igemm_desc(x, None, pw, out, n_img=n, h_in=h, w_in=w, h_out=h, w_out=w, stride=1, pad=0, upsample=2 + phase,
+                       bias=bias, splitk=1, tile=tile)
+        L.check(L.load().mvldm_igemm_fwd(C.byref(d), stream()))
     return out
 
 

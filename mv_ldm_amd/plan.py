@@ -152,6 +152,36 @@ class Builder:
         self._emit(op, name, 2.0 * m * pw.n_out * k_real, nbytes, (x, x2, pw.data, bias, row_bias, residual, out))
         return out
 
+    def conv_upsample_phases(self, x, pws, bias=None, name="upsample"):
+        """nearest-2x + 3x3 conv as four 2x2 phase convs on the low-resolution input (ops.upsample_phase_weights)"""
+        n, h, w, c0 = x.shape
+        out = self.empty(n, 2 * h, 2 * w, pws[0].n_out, dtype=x.dtype)
+        for phase, pw in enumerate(pws):
+            assert pw.ksize == 2 and pw.k_order == 1 and c0 == pw.c_pad
+            op = L.Op()
+            op.kind = L.OP_IGEMM
+            d = op.u.igemm
+            d.src0, d.src1, d.weight = ptr(x), None, ptr(pw.data)
+            d.bias, d.row_bias, d.residual, d.dst = ptr(bias), None, None, ptr(out)
+            d.c0, d.c1 = c0, 0
+            d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, h, w
+            d.ksize, d.stride, d.pad, d.upsample = 2, 1, 0, 2 + phase
+            d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
+            d.row_bias_ld = 0
+            d.epilogue, d.act_dtype, d.dst_dtype = L.EPI_NONE, dt(x), dt(out)
+            d.splitk, d.tile, d.out_scale = 1, 0, 1.0
+            d.dst_ld = 0
+            d.k_order = 1
+            d.workspace, d.workspace_bytes = None, 0
+            m = n * h * w
+            es = x.element_size()
+            nbytes = (pw.n_out * 4 * c0 + (m * c0 if phase == 0 else 0)) * es + m * pw.n_out * es
+            if self.record:
+                own = self.__dict__.get("_own_ptrs", ())
+                self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = (x if x.data_ptr() in own else None, None)
+            self._emit(op, f"{name}.p{phase}", 2.0 * m * pw.n_out * 4 * c0, nbytes, (x, pw.data, bias, out))
+        return out
+
     def linear(self, x, pw: PackedWeight, bias=None, *, residual=None, epilogue=L.EPI_NONE, out_dtype=None, out=None,
                name="linear", row_bias=None):
         """x: `[rows, c]`."""

@@ -386,3 +386,30 @@ def test_empty_and_degenerate_inputs(ops):
         ops.attention(q, q, q, 1, 63, ops.make_segments([5]), 5)             # head_dim not a multiple of 8
     with pytest.raises(MvldmError):
         ops.groupnorm(torch.empty(1, 2, 2, 64, dtype=dt_, device="cuda"), g, b, 48, 1e-5, False)   # 64 % 48 != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,c,cout,h,w,tile", [(2, 64, 64, 4, 4, 0), (3, 128, 96, 5, 7, 0), (5, 320, 320, 16, 16, 0), (9, 64, 320, 8, 8, 10),
+                                               (2, 128, 128, 33, 20, 7)],
+                         ids=["4x4", "odd_5x7", "320_16x16", "tile10", "tile7_ragged"])
+def test_upsample_conv_as_four_phase_convs(ops, dtype, n, c, cout, h, w, tile):
+    """nearest-2x + 3x3/pad-1 conv == four 2x2 convs on the low-resolution image with pre-summed taps
+    (ops.upsample_phase_weights): against F.interpolate + F.conv2d, and against the gather form of the same kernel"""
+    x = rnd((n, c, h, w), 51, dtype)
+    wt = rnd((cout, c, 3, 3), 52, dtype, 1 / math.sqrt(c * 9))
+    b = torch.randn(cout, generator=G(53)) * 0.1
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), wt.double(), b.double(), padding=1)
+    # the identity itself, in fp64 on the CPU (each phase is a 2x2 conv with padding chosen per parity)
+    wp = [t.double() for t in ops.upsample_phase_weights(wt)]          # (taps summed in fp32)
+    chk = torch.zeros_like(ref)
+    for ph, wph in enumerate(wp):
+        py, px = ph >> 1, ph & 1
+        xp = F.pad(x.double(), (1 - px, px, 1 - py, py))
+        chk[:, :, py::2, px::2] = F.conv2d(xp, wph, b.double())
+    assert (chk - ref).abs().max() < 1e-5
+    pws = [ops.pack_weight(t.cuda(), dtype) for t in ops.upsample_phase_weights(wt)]
+    y = ops.conv2d_upsample_phases(nhwc(x, dtype), pws, b.cuda(), tile=tile)
+    assert y.shape == (n, 2 * h, 2 * w, cout)
+    close(nchw(y), ref, dtype, "phases")
+    y_gather = ops.conv2d(nhwc(x, dtype), ops.pack_weight(wt.cuda(), dtype), b.cuda(), upsample=True)
+    close(nchw(y), nchw(y_gather), dtype, "phases vs gather")
