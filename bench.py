@@ -244,7 +244,7 @@ def main():
         tot_ms = sum(ms)
         ig = agg.get(OP_IGEMM, [1e-9, 0, 0, 0])
         achieved = ig[1] / (ig[0] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_bl_kernel (implicit-GEMM conv3x3/1x1/linear, all 183 launches of one UNet pass)",
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_bl_kernel (implicit-GEMM conv3x3/1x1/linear, all launches of one UNet pass)",
                            "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
                            "traffic": pmc_traffic(args, b), "algorithmic_bytes_per_launch": round(ig[2] / max(ig[3], 1)),
