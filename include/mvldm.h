@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MVLDM_ABI_VERSION 1
+#define MVLDM_ABI_VERSION 2
 
 typedef void* mvldm_stream_t; /* hipStream_t */
 
@@ -141,7 +141,7 @@ int mvldm_timestep_embed_fwd(const int64_t* timesteps, const float* freqs, void*
 int mvldm_eltwise_fwd(const void* x, void* y, size_t n, int op, int src_dtype, int dst_dtype, mvldm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused classifier-free-guidance compose + DDIM update (eta = 0, epsilon prediction, no clipping).
+ * Fused classifier-free-guidance compose + DDIM update (eta = 0, epsilon prediction).
  *   replaces  DiffusionWrapper.step's tail (src/model/diffusion_wrapper.py:444,451-453) and
  *             diffusers DDIMScheduler.step.
  *   eps  = eps_u + cfg_scale * (eps_c - eps_u)            (use_cfg) | eps_c
@@ -156,11 +156,15 @@ int mvldm_eltwise_fwd(const void* x, void* y, size_t n, int op, int src_dtype, i
  * captured graph serves every step.
  * If unet_in != NULL the new latents are also scattered (activation dtype) into channels [0,c) of
  * the UNet input rows cond_img[t] and uncond_img[t] ([n_img_total][hw][unet_in_c]).
+ * n_steps: rows of coef (the step index is clamped to [0, n_steps-1], so a replay past the end of the
+ * schedule never reads out of bounds).  clip_range > 0: diffusers `clip_sample=True` --
+ * x0 = clamp(x0, -clip_range, clip_range) before the update (`clip_sample_range`, default 1.0); 0 = off
+ * (the released config, config/model/scheduler/ddim.yaml:9).
  */
 int mvldm_ddim_cfg_step(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img,
                         const int32_t* uncond_img, int n_tgt, int hw, int c, float cfg_scale, const float* coef,
-                        const int32_t* step_ptr, void* unet_in, int unet_in_c, int unet_in_dtype,
-                        mvldm_stream_t stream);
+                        const int32_t* step_ptr, void* unet_in, int unet_in_c, int unet_in_dtype, int n_steps,
+                        float clip_range, mvldm_stream_t stream);
 /* step_ptr += 1; timesteps[tgt_rows[i]] = t_table[min(step, n_steps-1)] for i < n_rows (the
  * per-image timestep vector the UNet reads: context views stay at 0, diffusion_wrapper.py:419-428) */
 int mvldm_ddim_advance(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps,
@@ -168,12 +172,35 @@ int mvldm_ddim_advance(int32_t* step_ptr, const int64_t* t_table, int n_steps, i
 
 /* ------------------------------------------------------------------------------------------------
  * Layout plumbing at the boundary: NCHW fp32 <-> NHWC activation dtype with channel offset/padding.
- *   replaces the torch.concat input assembly of DiffusionWrapper.step (diffusion_wrapper.py:429-432).
+ *   replaces the torch.concat input assembly of DiffusionWrapper.step / .sample
+ *   (diffusion_wrapper.py:429-432,476-481), the `inputs * 2.0 - 1.0` / `(1 / 0.18215) * latents` /
+ *   `(image / 2 + 0.5).clamp(0, 1)` arithmetic around the VAE (:281,293,298).
+ * nchw_to_nhwc: dst[img_map ? img_map[i] : i][pix][dst_c_off + ch] = src[i][ch][pix] * scale + shift
+ *   (img_map: device int32 [n_img] or NULL).
  */
 int mvldm_nchw_to_nhwc(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off,
-                       int dst_dtype, mvldm_stream_t stream);
+                       int dst_dtype, float scale, float shift, const int32_t* img_map, mvldm_stream_t stream);
 int mvldm_nhwc_to_nchw(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off,
                        int src_dtype, float scale, float shift, int clamp01, mvldm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Camera ray grid of the latent image.   replaces DiffusionWrapper.ray_encode with the raw [origin | direction]
+ * encoding (diffusion_wrapper.py:301-322, generate_image_rays :169-190; src/geometry/projection.py:74-138:
+ * sample_image_grid, unproject, get_world_rays).  extrinsics: fp32 [n_cam][4][4] camera-to-world;
+ * intrinsics: fp32 [n_cam][3][3] normalised.  Per latent pixel (i, j): xy = ((j+.5)/w, (i+.5)/h),
+ * d = normalize(K^-1 [x y 1]), direction = R d, origin = translation.  Outputs (either may be NULL):
+ * out_nchw fp32 [n_cam][6][h*w]; out_nhwc: channels [nhwc_c_off, +6) of an NHWC buffer [..][h*w][nhwc_c]
+ * in nhwc_dtype, camera i -> image img_map[i] (NULL: i).
+ */
+int mvldm_ray_encode(const float* extrinsics, const float* intrinsics, int n_cam, int h, int w, float* out_nchw,
+                     void* out_nhwc, int nhwc_c, int nhwc_c_off, int nhwc_dtype, const int32_t* img_map,
+                     mvldm_stream_t stream);
+
+/* AutoencoderKL.encode(x).latent_dist.sample() * scale (diffusion_wrapper.py:283; diffusers
+ * DiagonalGaussianDistribution): moments fp32 NCHW [n][2c][hw] = [mean | logvar], noise / out fp32 [n][c][hw];
+ * out = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale. */
+int mvldm_posterior_sample(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale,
+                           mvldm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plans: a whole forward (UNet walk, VAE decoder, DDIM step) as a flat list of the ops above with
@@ -184,7 +211,7 @@ int mvldm_nhwc_to_nchw(const void* src, float* dst, int n_img, int c, int hw, in
 enum {
     MVLDM_OP_IGEMM = 1, MVLDM_OP_GROUPNORM, MVLDM_OP_LAYERNORM, MVLDM_OP_ATTENTION, MVLDM_OP_TIMESTEP_EMBED,
     MVLDM_OP_ELTWISE, MVLDM_OP_DDIM_STEP, MVLDM_OP_DDIM_ADVANCE, MVLDM_OP_NCHW_TO_NHWC, MVLDM_OP_NHWC_TO_NCHW,
-    MVLDM_OP_MEMCPY
+    MVLDM_OP_MEMCPY, MVLDM_OP_RAY_ENCODE, MVLDM_OP_POSTERIOR_SAMPLE
 };
 
 typedef struct mvldm_op {
@@ -203,11 +230,14 @@ typedef struct mvldm_op {
         struct { const void* x; void* y; size_t n; int32_t op, src_dtype, dst_dtype; } eltwise;
         struct { const float* eps; const float* x_t; float* x_next; const int32_t* cond_img; const int32_t* uncond_img;
                  const float* coef; const int32_t* step_ptr; void* unet_in;
-                 int32_t n_tgt, hw, c, unet_in_c, unet_in_dtype; float cfg_scale; } ddim;
+                 int32_t n_tgt, hw, c, unet_in_c, unet_in_dtype; float cfg_scale; int32_t n_steps; float clip_range; } ddim;
         struct { int32_t* step_ptr; const int64_t* t_table; int64_t* timesteps; const int32_t* tgt_rows;
                  int32_t n_steps, n_rows; } advance;
         struct { const void* src; void* dst; int32_t n_img, c, hw, other_c, other_c_off, dtype, clamp01;
-                 float scale, shift; } layout;
+                 float scale, shift; const int32_t* img_map; } layout;
+        struct { const float* extrinsics; const float* intrinsics; float* out_nchw; void* out_nhwc; const int32_t* img_map;
+                 int32_t n_cam, h, w, nhwc_c, nhwc_c_off, nhwc_dtype; } rays;
+        struct { const float* moments; const float* noise; float* out; int32_t n, c, hw; float scale; } posterior;
         struct { const void* src; void* dst; size_t bytes; } memcpy_;
     } u;
 } mvldm_op;

@@ -30,13 +30,16 @@ def _stale(target: Path, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
+    flags = list(FLAGS)
+    if os.environ.get("MVLDM_EXPERIMENTS") == "1":      # tools/ only: compiles the MVLDM_IGEMM_FAKE roofline knobs in
+        flags.append("-DMVLDM_EXPERIMENTS")
     objs, jobs = [], []
     for src in SOURCES:
         s = CSRC / src
         o = CSRC / (s.stem + ".o")
         objs.append(o)
         if force or _stale(o, [s, *HEADERS]):
-            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", str(s), "-o", str(o)]
+            cmd = [hipcc, *flags, "-x", "hip", "-c", str(s), "-o", str(o)]
             jobs.append(cmd)
     if jobs:
         def run(cmd):

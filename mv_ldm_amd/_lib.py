@@ -11,13 +11,14 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmvldm_hip.so"
 
+ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_GEGLU = 0, 1, 2
 ELT_COPY, ELT_SILU = 0, 1
 GN_MAX_CHUNKS = 32
 
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_TIMESTEP_EMBED, OP_ELTWISE, OP_DDIM_STEP, OP_DDIM_ADVANCE,
- OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY) = range(1, 12)
+ OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY, OP_RAY_ENCODE, OP_POSTERIOR_SAMPLE) = range(1, 14)
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 
@@ -60,7 +61,8 @@ class _Eltwise(C.Structure):
 class _Ddim(C.Structure):
     _fields_ = [("eps", vp), ("x_t", vp), ("x_next", vp), ("cond_img", vp), ("uncond_img", vp), ("coef", vp),
                 ("step_ptr", vp), ("unet_in", vp),
-                ("n_tgt", i32), ("hw", i32), ("c", i32), ("unet_in_c", i32), ("unet_in_dtype", i32), ("cfg_scale", f32)]
+                ("n_tgt", i32), ("hw", i32), ("c", i32), ("unet_in_c", i32), ("unet_in_dtype", i32), ("cfg_scale", f32),
+                ("n_steps", i32), ("clip_range", f32)]
 
 
 class _Advance(C.Structure):
@@ -69,7 +71,16 @@ class _Advance(C.Structure):
 
 class _Layout(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("n_img", i32), ("c", i32), ("hw", i32), ("other_c", i32),
-                ("other_c_off", i32), ("dtype", i32), ("clamp01", i32), ("scale", f32), ("shift", f32)]
+                ("other_c_off", i32), ("dtype", i32), ("clamp01", i32), ("scale", f32), ("shift", f32), ("img_map", vp)]
+
+
+class _Rays(C.Structure):
+    _fields_ = [("extrinsics", vp), ("intrinsics", vp), ("out_nchw", vp), ("out_nhwc", vp), ("img_map", vp),
+                ("n_cam", i32), ("h", i32), ("w", i32), ("nhwc_c", i32), ("nhwc_c_off", i32), ("nhwc_dtype", i32)]
+
+
+class _Posterior(C.Structure):
+    _fields_ = [("moments", vp), ("noise", vp), ("out", vp), ("n", i32), ("c", i32), ("hw", i32), ("scale", f32)]
 
 
 class _Memcpy(C.Structure):
@@ -79,7 +90,7 @@ class _Memcpy(C.Structure):
 class _OpUnion(C.Union):
     _fields_ = [("igemm", IgemmDesc), ("groupnorm", _GroupNorm), ("layernorm", _LayerNorm), ("attention", _Attention),
                 ("temb", _Temb), ("eltwise", _Eltwise), ("ddim", _Ddim), ("advance", _Advance), ("layout", _Layout),
-                ("memcpy_", _Memcpy)]
+                ("memcpy_", _Memcpy), ("rays", _Rays), ("posterior", _Posterior)]
 
 
 class Op(C.Structure):
@@ -99,9 +110,11 @@ SIGNATURES = {
     "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp]),
     "mvldm_timestep_embed_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mvldm_eltwise_fwd": (C.c_int, [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp]),
-    "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
     "mvldm_ddim_advance": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp]),
-    "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, vp, vp]),
+    "mvldm_ray_encode": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "mvldm_posterior_sample": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
     "mvldm_nhwc_to_nchw": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, C.c_int, vp]),
     "mvldm_op_run": (C.c_int, [C.POINTER(Op), vp]),
     "mvldm_plan_create": (C.c_int, [C.POINTER(Op), C.c_int, C.POINTER(vp)]),
@@ -135,7 +148,7 @@ def load(required: bool = True):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.mvldm_abi_version() != 1:
+    if lib.mvldm_abi_version() != ABI_VERSION:
         raise MvldmError("libmvldm_hip.so ABI version mismatch")
     _lib = lib
     return lib

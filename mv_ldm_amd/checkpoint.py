@@ -36,6 +36,32 @@ def read_state_dict(path) -> Dict[str, torch.Tensor]:
     return obj
 
 
+def find_local_weights(path, subfolder: str) -> Optional[Path]:
+    """the weight file `from_pretrained(path, subfolder=...)` would read from a LOCAL diffusers snapshot:
+    `<path>/<subfolder>/diffusion_pytorch_model.{safetensors,bin}`, or `path` itself when it is a weight file.
+    None when `path` is a hub id / does not exist (there is no hub access offline)."""
+    if path is None:
+        return None
+    p = Path(str(path))
+    if p.is_file() and p.suffix in (".safetensors", ".bin", ".ckpt", ".pt", ".pth"):
+        return p
+    for name in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin"):
+        f = p / subfolder / name
+        if f.is_file():
+            return f
+    return None
+
+
+def load_unet_checkpoint(unet, path, strict: bool = True) -> "LoadReport":
+    """a stand-alone diffusers UNet file (`unet/diffusion_pytorch_model.safetensors` / `.bin`).  Like the reference
+    (mvunet.py:66-72) the caller replaces conv_in / conv_out AFTER this load, so their SD shapes (4 in / 4 out) must fit
+    the module as built by `from_pretrained` -- mismatching conv_in/conv_out entries are skipped, not an error."""
+    sd = read_state_dict(path)
+    own = unet.state_dict()
+    sd = {k: v for k, v in sd.items() if not (k.startswith(("conv_in.", "conv_out.")) and k in own and own[k].shape != v.shape)}
+    return load_module_state(unet, sd, strict, "unet")
+
+
 def split_wrapper_state(sd: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
     """`denoiser.* / autoencoder.*` of a DiffusionWrapper checkpoint -> {"denoiser": {...}, "autoencoder": {...},
     "other": {...}} with the prefixes removed.  A state dict without those prefixes is returned under "other"."""

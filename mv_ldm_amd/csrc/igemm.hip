@@ -15,6 +15,7 @@
 // Workgroup -> tile mapping is XCD-aware: each of the 8 XCDs owns a contiguous range of
 // (split, n-tile, m-tile) ids with m fastest, so one weight tile is streamed from HBM by one XCD only.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -1014,7 +1015,14 @@ static const int kEnvTarget = env_int("MVLDM_IGEMM_TARGET", 0);
 static const int kEnvSync = env_int("MVLDM_IGEMM_SYNC", 0);
 static const int kEnvPx = env_int("MVLDM_IGEMM_PX", 0);
 static const int kEnvNoStage = env_int("MVLDM_IGEMM_NOSTAGE", 0);
+// MVLDM_IGEMM_FAKE makes every conv/linear return WRONG results (operands read as zeros, epilogue skipped): it exists
+// for the roofline experiments of tools/fake_probe.sh only and is compiled in only with -DMVLDM_EXPERIMENTS
+// (MVLDM_EXPERIMENTS=1 python -m mv_ldm_amd._build --force); the product library ignores the variable.
+#ifdef MVLDM_EXPERIMENTS
 static const int kEnvFake = env_int("MVLDM_IGEMM_FAKE", 0);
+#else
+static constexpr int kEnvFake = 0;
+#endif
 
 template <typename KernT> static int launch_kernel(KernT kern, bool& attr_done, int smem, int blocks, int threads,
                                                    const IgemmParams& p, hipStream_t s) {
@@ -1236,6 +1244,16 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     const double bw = (double)d.n_pad * d.k_pad * es;
     p.use_bl = d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !kEnvSync &&
                b0 < 4.0e9 && b1 < 4.0e9 && bw < 4.0e9;
+    if (d.act_dtype != MVLDM_F32 && d.k_order == 1 && !t_force_sync && !kEnvSync && !p.use_bl) {
+        // a source or the weight is beyond the 32-bit buffer-offset range of the LDS-DMA loop: the launch is still correct
+        // on the 64-bit-pointer register-prefetch loop, but 3-5x slower -- say so once (callers chunk the batch: vae._chunks)
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "[mvldm] igemm: operand of %.2f GB exceeds the 4 GB range of the fast 16-bit loop; using the slower "
+                            "64-bit-address loop (split the batch to avoid this)\n", std::max(std::max(b0, b1), bw) / 1e9);
+        }
+    }
     p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
     p.fake = kEnvFake;
     if (kEnvFake & 1) p.src0_bytes = p.src1_bytes = 0;   // EXPERIMENT ONLY: every A piece fails the range check (zeros, no L2 traffic)

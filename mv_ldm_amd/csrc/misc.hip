@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ eps
                                                    const int32_t* __restrict__ uncond_img, int n_tgt, int hw, int c,
                                                    float cfg_scale, const float* __restrict__ coef,
                                                    const int32_t* __restrict__ step_ptr, TU* __restrict__ unet_in,
-                                                   int unet_in_c) {
-    const int step = *step_ptr;
+                                                   int unet_in_c, int n_steps, float clip_range) {
+    // a replay past the end of the schedule re-applies the last step's coefficients instead of reading out of bounds
+    const int step = min(max(*step_ptr, 0), n_steps - 1);
     const float sb = coef[step * 4 + 0], sa = coef[step * 4 + 1], sp = coef[step * 4 + 2], sd = coef[step * 4 + 3];
     const size_t per = (size_t)hw * c, total = (size_t)n_tgt * per;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ eps
             e = __fadd_rn(eu, __fmul_rn(cfg_scale, __fsub_rn(ec, eu)));
         }
         const float x = x_t[idx];
-        const float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(sb, e)), sa);
+        float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(sb, e)), sa);
+        if (clip_range > 0.f) x0 = fminf(fmaxf(x0, -clip_range), clip_range);   // diffusers `clip_sample` (x0 only; eps is kept)
         const float xn = __fadd_rn(__fmul_rn(sp, x0), __fmul_rn(sd, e));
         x_next[idx] = xn;
         if (unet_in) {
@@ -75,14 +77,16 @@ __global__ void ddim_advance_kernel(int32_t* step_ptr, const int64_t* t_table, i
 
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_img,
-                                                           int c, int hw, int dst_c, int dst_c_off) {
+                                                           int c, int hw, int dst_c, int dst_c_off, float scale, float shift,
+                                                           const int32_t* __restrict__ img_map) {
     const size_t total = (size_t)n_img * hw * c;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         // idx enumerates the destination (pixel-major, channel fastest)
         const int ch = (int)(idx % c);
         const size_t pi = idx / c;
         const int pix = (int)(pi % hw), img = (int)(pi / hw);
-        dst[((size_t)img * hw + pix) * dst_c + dst_c_off + ch] = from_f32<T>(src[((size_t)img * c + ch) * hw + pix]);
+        const int dimg = img_map ? img_map[img] : img;     // source image i lands in destination image img_map[i]
+        dst[((size_t)dimg * hw + pix) * dst_c + dst_c_off + ch] = from_f32<T>(src[((size_t)img * c + ch) * hw + pix] * scale + shift);
     }
 }
 
@@ -102,7 +106,93 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
     }
 }
 
+
+// Per-pixel camera rays of the latent grid (DiffusionWrapper.ray_encode, diffusion_wrapper.py:301-322 ->
+// generate_image_rays :169-190 -> sample_image_grid / unproject / get_world_rays, projection.py:74-138):
+//   xy = ((j + .5)/w, (i + .5)/h);  d = normalize(K^-1 [x, y, 1]);  d_world = R d;  origin = c2w translation.
+// One thread per (camera, pixel); K^-1 by the adjugate (fp32).  Output channels: origin xyz, direction xyz.
+// Either / both of: fp32 NCHW [n_cam][6][hw] (the reference's `ray_encodings` tensor) and a slice
+// [c_off, c_off+6) of an NHWC activation buffer (the UNet input), image i -> row block img_map[i].
+template <typename T>
+__global__ __launch_bounds__(256) void ray_kernel(const float* __restrict__ extr, const float* __restrict__ intr, int n_cam,
+                                                  int h, int w, float* __restrict__ out_nchw, T* __restrict__ out_nhwc,
+                                                  int nhwc_c, int nhwc_c_off, const int32_t* __restrict__ img_map) {
+    const int hw = h * w;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_cam * hw) return;
+    const int cam = idx / hw, pix = idx - cam * hw;
+    const int i = pix / w, j = pix - i * w;
+    const float* K = intr + cam * 9;
+    const float* E = extr + cam * 16;
+    const float a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], hh = K[7], k = K[8];
+    const float A = e * k - f * hh, B = -(d * k - f * g), C = d * hh - e * g;
+    const float det = a * A + b * B + c * C;
+    const float id = 1.0f / det;
+    const float inv[9] = {A * id, -(b * k - c * hh) * id, (b * f - c * e) * id,
+                          B * id, (a * k - c * g) * id, -(a * f - c * d) * id,
+                          C * id, -(a * hh - b * g) * id, (a * e - b * d) * id};
+    const float x = ((float)j + 0.5f) / (float)w, y = ((float)i + 0.5f) / (float)h;
+    float dx = inv[0] * x + inv[1] * y + inv[2];
+    float dy = inv[3] * x + inv[4] * y + inv[5];
+    float dz = inv[6] * x + inv[7] * y + inv[8];
+    const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= n; dy /= n; dz /= n;
+    float v[6];
+    v[0] = E[3]; v[1] = E[7]; v[2] = E[11];
+    v[3] = E[0] * dx + E[1] * dy + E[2] * dz;
+    v[4] = E[4] * dx + E[5] * dy + E[6] * dz;
+    v[5] = E[8] * dx + E[9] * dy + E[10] * dz;
+    if (out_nchw) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) out_nchw[((size_t)cam * 6 + q) * hw + pix] = v[q];
+    }
+    if (out_nhwc) {
+        const int dimg = img_map ? img_map[cam] : cam;
+        T* o = out_nhwc + ((size_t)dimg * hw + pix) * nhwc_c + nhwc_c_off;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[q] = from_f32<T>(v[q]);
+    }
+}
+
+// DiagonalGaussianDistribution.sample() of diffusers' AutoencoderKL.encode (diffusion_wrapper.py:283):
+// moments fp32 NCHW [n][2c][hw] = [mean | logvar]; z = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale
+__global__ __launch_bounds__(256) void posterior_sample_kernel(const float* __restrict__ moments, const float* __restrict__ noise,
+                                                               float* __restrict__ out, int n, int c, int hw, float scale) {
+    const size_t total = (size_t)n * c * hw;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t per = (size_t)c * hw;
+        const int img = (int)(idx / per);
+        const size_t rem = idx - (size_t)img * per;
+        const float mean = moments[(size_t)img * 2 * per + rem];
+        const float logvar = fminf(fmaxf(moments[(size_t)img * 2 * per + per + rem], -30.f), 20.f);
+        const float stdv = expf(0.5f * logvar);
+        out[idx] = __fmul_rn(__fadd_rn(mean, __fmul_rn(stdv, noise[idx])), scale);
+    }
+}
+
 static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
+
+int ray_run(const float* extr, const float* intr, int n_cam, int h, int w, float* out_nchw, void* out_nhwc, int nhwc_c,
+            int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, hipStream_t s) {
+    MVLDM_REQUIRE(extr && intr && (out_nchw || out_nhwc), "ray_encode: null pointer");
+    MVLDM_REQUIRE(!out_nhwc || nhwc_c_off + 6 <= nhwc_c, "ray_encode: channel slice [%d, %d) outside %d", nhwc_c_off, nhwc_c_off + 6, nhwc_c);
+    const size_t total = (size_t)n_cam * h * w;
+    if (total == 0) return MVLDM_OK;
+    return dispatch_dtype(out_nhwc ? nhwc_dtype : MVLDM_F32, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(ray_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, extr, intr, n_cam, h, w, out_nchw,
+                           reinterpret_cast<T*>(out_nhwc), nhwc_c, nhwc_c_off, img_map);
+        return check_launch();
+    });
+}
+
+int posterior_run(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale, hipStream_t s) {
+    MVLDM_REQUIRE(moments && noise && out, "posterior_sample: null pointer");
+    const size_t total = (size_t)n * c * hw;
+    if (total == 0) return MVLDM_OK;
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3(grid_for(total)), dim3(256), 0, s, moments, noise, out, n, c, hw, scale);
+    return check_launch();
+}
 
 int temb_run(const int64_t* ts, const float* freqs, void* out, int n, int dim, int flip, int dst_dtype, hipStream_t s) {
     MVLDM_REQUIRE(ts && freqs && out && dim % 2 == 0, "timestep_embed: bad arguments");
@@ -130,14 +220,14 @@ int eltwise_run(const void* x, void* y, size_t n, int op, int src_dtype, int dst
 
 int ddim_run(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img, const int32_t* uncond_img,
              int n_tgt, int hw, int c, float cfg_scale, const float* coef, const int32_t* step_ptr, void* unet_in,
-             int unet_in_c, int unet_in_dtype, hipStream_t s) {
-    MVLDM_REQUIRE(eps && x_t && x_next && cond_img && coef && step_ptr, "ddim: null pointer");
+             int unet_in_c, int unet_in_dtype, int n_steps, float clip_range, hipStream_t s) {
+    MVLDM_REQUIRE(eps && x_t && x_next && cond_img && coef && step_ptr && n_steps >= 1, "ddim: null pointer / n_steps");
     const size_t total = (size_t)n_tgt * hw * c;
     if (total == 0) return MVLDM_OK;
     return dispatch_dtype(unet_in_dtype, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL(ddim_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, eps, x_t, x_next, cond_img, uncond_img,
-                           n_tgt, hw, c, cfg_scale, coef, step_ptr, reinterpret_cast<T*>(unet_in), unet_in_c);
+                           n_tgt, hw, c, cfg_scale, coef, step_ptr, reinterpret_cast<T*>(unet_in), unet_in_c, n_steps, clip_range);
         return check_launch();
     });
 }
@@ -150,13 +240,14 @@ int advance_run(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t*
     return check_launch();
 }
 
-int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off, int dst_dtype, hipStream_t s) {
+int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off, int dst_dtype, float scale,
+                float shift, const int32_t* img_map, hipStream_t s) {
     MVLDM_REQUIRE(src && dst && dst_c_off + c <= dst_c, "nchw_to_nhwc: bad arguments");
     const size_t total = (size_t)n_img * hw * c;
     if (total == 0) return MVLDM_OK;
     return dispatch_dtype(dst_dtype, [&](auto t) {
         using T = decltype(t);
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, src, reinterpret_cast<T*>(dst), n_img, c, hw, dst_c, dst_c_off);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, src, reinterpret_cast<T*>(dst), n_img, c, hw, dst_c, dst_c_off, scale, shift, img_map);
         return check_launch();
     });
 }
@@ -186,17 +277,26 @@ extern "C" int mvldm_eltwise_fwd(const void* x, void* y, size_t n, int op, int s
 extern "C" int mvldm_ddim_cfg_step(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img,
                                    const int32_t* uncond_img, int n_tgt, int hw, int c, float cfg_scale, const float* coef,
                                    const int32_t* step_ptr, void* unet_in, int unet_in_c, int unet_in_dtype,
-                                   mvldm_stream_t stream) {
+                                   int n_steps, float clip_range, mvldm_stream_t stream) {
     return ddim_run(eps, x_t, x_next, cond_img, uncond_img, n_tgt, hw, c, cfg_scale, coef, step_ptr, unet_in, unet_in_c,
-                    unet_in_dtype, (hipStream_t)stream);
+                    unet_in_dtype, n_steps, clip_range, (hipStream_t)stream);
 }
 extern "C" int mvldm_ddim_advance(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps,
                                   const int32_t* tgt_rows, int n_rows, mvldm_stream_t stream) {
     return advance_run(step_ptr, t_table, n_steps, timesteps, tgt_rows, n_rows, (hipStream_t)stream);
 }
 extern "C" int mvldm_nchw_to_nhwc(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off,
-                                  int dst_dtype, mvldm_stream_t stream) {
-    return to_nhwc_run(src, dst, n_img, c, hw, dst_c, dst_c_off, dst_dtype, (hipStream_t)stream);
+                                  int dst_dtype, float scale, float shift, const int32_t* img_map, mvldm_stream_t stream) {
+    return to_nhwc_run(src, dst, n_img, c, hw, dst_c, dst_c_off, dst_dtype, scale, shift, img_map, (hipStream_t)stream);
+}
+extern "C" int mvldm_ray_encode(const float* extrinsics, const float* intrinsics, int n_cam, int h, int w, float* out_nchw,
+                                void* out_nhwc, int nhwc_c, int nhwc_c_off, int nhwc_dtype, const int32_t* img_map,
+                                mvldm_stream_t stream) {
+    return ray_run(extrinsics, intrinsics, n_cam, h, w, out_nchw, out_nhwc, nhwc_c, nhwc_c_off, nhwc_dtype, img_map, (hipStream_t)stream);
+}
+extern "C" int mvldm_posterior_sample(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale,
+                                      mvldm_stream_t stream) {
+    return posterior_run(moments, noise, out, n, c, hw, scale, (hipStream_t)stream);
 }
 extern "C" int mvldm_nhwc_to_nchw(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off,
                                   int src_dtype, float scale, float shift, int clamp01, mvldm_stream_t stream) {

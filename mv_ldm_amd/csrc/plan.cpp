@@ -17,10 +17,14 @@ int temb_run(const int64_t* ts, const float* freqs, void* out, int n, int dim, i
 int eltwise_run(const void* x, void* y, size_t n, int op, int src_dtype, int dst_dtype, hipStream_t s);
 int ddim_run(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img, const int32_t* uncond_img,
              int n_tgt, int hw, int c, float cfg_scale, const float* coef, const int32_t* step_ptr, void* unet_in,
-             int unet_in_c, int unet_in_dtype, hipStream_t s);
+             int unet_in_c, int unet_in_dtype, int n_steps, float clip_range, hipStream_t s);
 int advance_run(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps, const int32_t* tgt_rows,
                 int n_rows, hipStream_t s);
-int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off, int dst_dtype, hipStream_t s);
+int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off, int dst_dtype, float scale,
+                float shift, const int32_t* img_map, hipStream_t s);
+int ray_run(const float* extr, const float* intr, int n_cam, int h, int w, float* out_nchw, void* out_nhwc, int nhwc_c,
+            int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, hipStream_t s);
+int posterior_run(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale, hipStream_t s);
 int to_nchw_run(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off, int src_dtype, float scale,
                 float shift, int clamp01, hipStream_t s);
 
@@ -52,7 +56,7 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         case MVLDM_OP_DDIM_STEP: {
             const auto& d = op.u.ddim;
             return ddim_run(d.eps, d.x_t, d.x_next, d.cond_img, d.uncond_img, d.n_tgt, d.hw, d.c, d.cfg_scale, d.coef,
-                            d.step_ptr, d.unet_in, d.unet_in_c, d.unet_in_dtype, s);
+                            d.step_ptr, d.unet_in, d.unet_in_c, d.unet_in_dtype, d.n_steps, d.clip_range, s);
         }
         case MVLDM_OP_DDIM_ADVANCE: {
             const auto& a = op.u.advance;
@@ -60,12 +64,22 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         }
         case MVLDM_OP_NCHW_TO_NHWC: {
             const auto& l = op.u.layout;
-            return to_nhwc_run(reinterpret_cast<const float*>(l.src), l.dst, l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype, s);
+            return to_nhwc_run(reinterpret_cast<const float*>(l.src), l.dst, l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype,
+                               l.scale, l.shift, l.img_map, s);
         }
         case MVLDM_OP_NHWC_TO_NCHW: {
             const auto& l = op.u.layout;
             return to_nchw_run(l.src, reinterpret_cast<float*>(l.dst), l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype,
                                l.scale, l.shift, l.clamp01, s);
+        }
+        case MVLDM_OP_RAY_ENCODE: {
+            const auto& r = op.u.rays;
+            return ray_run(r.extrinsics, r.intrinsics, r.n_cam, r.h, r.w, r.out_nchw, r.out_nhwc, r.nhwc_c, r.nhwc_c_off,
+                           r.nhwc_dtype, r.img_map, s);
+        }
+        case MVLDM_OP_POSTERIOR_SAMPLE: {
+            const auto& q = op.u.posterior;
+            return posterior_run(q.moments, q.noise, q.out, q.n, q.c, q.hw, q.scale, s);
         }
         case MVLDM_OP_MEMCPY: {
             const auto& m = op.u.memcpy_;

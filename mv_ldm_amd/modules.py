@@ -38,6 +38,12 @@ def _ver(*params):
     return tuple((p.data_ptr(), p._version, str(p.device)) for p in params if p is not None)
 
 
+def weights_version(module) -> int:
+    """fingerprint of every parameter's (storage, in-place version): recorded plans hold raw pointers to PACKED copies of
+    the weights, so they are keyed on this and re-recorded after `load_state_dict`, an optimizer step, an EMA copy ..."""
+    return hash(tuple((p.data_ptr(), p._version) for p in module.parameters()))
+
+
 class _PackMixin:
     """lazy, version-checked cache of kernel-layout copies of the module's parameters"""
 
@@ -611,14 +617,25 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = Conv2d(boc[0], out_channels, 3, padding=1)
 
     @classmethod
-    def from_pretrained(cls, path, subfolder="unet", config_overrides=None, state_dict=None):
-        """Builds the SD-2.1 topology.  No hub access exists offline: pass `state_dict` (diffusers key
-        layout) to load weights, otherwise the modules keep torch's default random init."""
+    def from_pretrained(cls, path, subfolder="unet", config_overrides=None, state_dict=None, allow_random_init=False):
+        """Builds the SD-2.1 topology.  Weights: `state_dict` (diffusers key layout), or a LOCAL snapshot at `path`
+        (`<path>/<subfolder>/diffusion_pytorch_model.safetensors|.bin`); no hub access exists offline, so anything
+        else keeps torch's random init -- with a warning unless `allow_random_init` (the reference loads SD-2.1 here,
+        mvunet.py:66)."""
         cfg = dict(SD21_UNET_CONFIG)
         cfg.update(config_overrides or {})
         m = cls(**cfg)
         if state_dict is not None:
             m.load_state_dict(state_dict)
+            return m
+        from .checkpoint import find_local_weights, load_unet_checkpoint
+        f = find_local_weights(path, subfolder)
+        if f is not None:
+            load_unet_checkpoint(m, f)
+        elif not allow_random_init:
+            import warnings
+            warnings.warn(f"UNet2DConditionModel.from_pretrained({path!r}): no local weights found and no state_dict given "
+                          "-- the module keeps RANDOM initial weights (pass allow_random_init=True to silence)", stacklevel=2)
         return m
 
     def enable_xformers_memory_efficient_attention(self):  # diffusion_wrapper.py:147: already flash-style

@@ -29,7 +29,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from .modules import (Attention, Builder, Conv2d, FeedForward, GroupNorm, LayerNorm, UNet2DConditionModel, _PackMixin,
-                      _segments, eager_builder)
+                      _segments, eager_builder, weights_version)
 from .runtime import from_nhwc, get_compute_dtype, require_gpu, to_nhwc
 
 
@@ -73,6 +73,7 @@ class MultiViewUNetCfg:
     # hands a diffusers-layout state dict to `from_pretrained` (no hub access offline)
     pretrained_overrides: Optional[dict] = None
     pretrained_state_dict: Optional[dict] = None
+    allow_random_init: bool = False          # silence the "no pretrained weights found" warning (benches / tests)
 
 
 # ------------------------------------------------------------------------------------------ MV attention
@@ -182,7 +183,8 @@ class MultiViewUNet(Denoiser, _PackMixin):
         else:
             self.unet = UNet2DConditionModel.from_pretrained(self.pretrained_from, subfolder="unet",
                                                              config_overrides=getattr(cfg, "pretrained_overrides", None),
-                                                             state_dict=getattr(cfg, "pretrained_state_dict", None))
+                                                             state_dict=getattr(cfg, "pretrained_state_dict", None),
+                                                             allow_random_init=getattr(cfg, "allow_random_init", False))
             c0 = self.unet.config.block_out_channels[0]
             self.unet.conv_in = Conv2d(in_channels, c0, kernel_size=3, padding=1)
             self.unet.conv_out = Conv2d(c0, out_channels, kernel_size=3, padding=1)
@@ -327,7 +329,7 @@ class MultiViewUNet(Denoiser, _PackMixin):
         dev = next(self.parameters()).device
         key = (b_scenes, views, h, w, dtype, str(dev), graph)
         st = self._plans.get(key)
-        if st is not None:
+        if st is not None and st["weights_version"] == self.weights_version():
             return st
         n = b_scenes * views
         bld = Builder(dev, dtype, record=True)
@@ -342,9 +344,12 @@ class MultiViewUNet(Denoiser, _PackMixin):
         plan = bld.finalize()
         if graph:
             plan.capture()
-        st = dict(plan=plan, lat=lat, ts=ts, out=out, graph=graph)
+        st = dict(plan=plan, lat=lat, ts=ts, out=out, graph=graph, weights_version=self.weights_version())
         self._plans[key] = st
         return st
+
+    def weights_version(self) -> int:
+        return weights_version(self)
 
     def forward(self, latents, timestep, cond_state=None):
         """latents [b, v, c, h, w]; timestep int64 [b] or [b, v] -> [b, v, out_channels, h, w] (fp32)."""

@@ -261,15 +261,44 @@ def convert(x, out_dtype):
 
 
 def nchw_to_nhwc(src: torch.Tensor, dtype, dst: Optional[torch.Tensor] = None, c_off: int = 0,
-                 dst_c: Optional[int] = None) -> torch.Tensor:
-    """fp32 NCHW `[n, c, h, w]` -> NHWC `[n, h, w, dst_c]` (channels [c_off, c_off+c) written)."""
+                 dst_c: Optional[int] = None, scale: float = 1.0, shift: float = 0.0,
+                 img_map: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 NCHW `[n, c, h, w]` -> NHWC `[n, h, w, dst_c]` (channels [c_off, c_off+c) written), `* scale + shift`;
+    `img_map` (int32 `[n]`): source image i lands in destination image img_map[i]."""
     assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous()
     n, c, h, w = src.shape
     if dst is None:
         dst_c = c if dst_c is None else dst_c
         dst = torch.zeros(n, h, w, dst_c, dtype=dtype, device=src.device)
-    L.check(L.load().mvldm_nchw_to_nhwc(src.data_ptr(), dst.data_ptr(), n, c, h * w, dst.shape[-1], c_off, dt(dst), stream()))
+    L.check(L.load().mvldm_nchw_to_nhwc(src.data_ptr(), dst.data_ptr(), n, c, h * w, dst.shape[-1], c_off, dt(dst), scale, shift,
+                                        ptr(img_map), stream()))
     return dst
+
+
+def ray_encode(extrinsics: torch.Tensor, intrinsics: torch.Tensor, h: int, w: int, out_nchw: Optional[torch.Tensor] = None,
+               out_nhwc: Optional[torch.Tensor] = None, c_off: int = 0, img_map: Optional[torch.Tensor] = None):
+    """extrinsics fp32 `[n, 4, 4]` (camera-to-world), intrinsics fp32 `[n, 3, 3]` on the device -> per-pixel
+    [origin | direction] of the `h x w` latent grid: fp32 `[n, 6, h, w]` and/or channels [c_off, c_off+6) of an NHWC
+    buffer `[.., h, w, C]` (camera i -> image img_map[i])."""
+    n = extrinsics.shape[0]
+    assert extrinsics.is_cuda and extrinsics.dtype == torch.float32 and extrinsics.is_contiguous() and extrinsics.shape[1:] == (4, 4)
+    assert intrinsics.dtype == torch.float32 and intrinsics.is_contiguous() and intrinsics.shape == (n, 3, 3)
+    if out_nchw is None and out_nhwc is None:
+        out_nchw = torch.empty(n, 6, h, w, dtype=torch.float32, device=extrinsics.device)
+    L.check(L.load().mvldm_ray_encode(extrinsics.data_ptr(), intrinsics.data_ptr(), n, h, w, ptr(out_nchw), ptr(out_nhwc),
+                                      0 if out_nhwc is None else out_nhwc.shape[-1], c_off,
+                                      L.F32 if out_nhwc is None else dt(out_nhwc), ptr(img_map), stream()))
+    return out_nchw if out_nchw is not None else out_nhwc
+
+
+def posterior_sample(moments: torch.Tensor, noise: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """moments fp32 NCHW `[n, 2c, h, w]` = [mean | logvar]; `(mean + exp(0.5 clamp(logvar, -30, 20)) * noise) * scale`"""
+    n, c2, h, w = moments.shape
+    assert moments.is_cuda and moments.dtype == torch.float32 and moments.is_contiguous()
+    assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.numel() == n * (c2 // 2) * h * w
+    out = torch.empty(n, c2 // 2, h, w, dtype=torch.float32, device=moments.device)
+    L.check(L.load().mvldm_posterior_sample(moments.data_ptr(), noise.data_ptr(), out.data_ptr(), n, c2 // 2, h * w, scale, stream()))
+    return out
 
 
 def nhwc_to_nchw(src: torch.Tensor, c: Optional[int] = None, c_off: int = 0, scale=1.0, shift=0.0,
@@ -283,12 +312,13 @@ def nhwc_to_nchw(src: torch.Tensor, c: Optional[int] = None, c_off: int = 0, sca
     return out
 
 
-def ddim_cfg_step(eps, x_t, cond_img, uncond_img, cfg_scale, coef, step_ptr, unet_in=None) -> torch.Tensor:
-    """eps: fp32 NHWC `[n_img, h, w, c]`; x_t: fp32 NHWC `[n_tgt, h, w, c]` -> x_{t-1} (same shape)."""
+def ddim_cfg_step(eps, x_t, cond_img, uncond_img, cfg_scale, coef, step_ptr, unet_in=None, clip_range: float = 0.0) -> torch.Tensor:
+    """eps: fp32 NHWC `[n_img, h, w, c]`; x_t: fp32 NHWC `[n_tgt, h, w, c]` -> x_{t-1} (same shape).
+    coef: fp32 `[n_steps, 4]`; `clip_range` > 0 clamps the predicted x0 (diffusers `clip_sample`)."""
     n_tgt, h, w, c = x_t.shape
     out = torch.empty_like(x_t)
     L.check(L.load().mvldm_ddim_cfg_step(eps.data_ptr(), x_t.data_ptr(), out.data_ptr(), cond_img.data_ptr(), ptr(uncond_img),
                                          n_tgt, h * w, c, cfg_scale, coef.data_ptr(), step_ptr.data_ptr(), ptr(unet_in),
                                          0 if unet_in is None else unet_in.shape[-1],
-                                         dt(unet_in) if unet_in is not None else L.F32, stream()))
+                                         dt(unet_in) if unet_in is not None else L.F32, coef.shape[0], clip_range, stream()))
     return out

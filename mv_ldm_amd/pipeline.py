@@ -2,8 +2,10 @@
 (src/model/diffusion_wrapper.py) on the HIP path.
 
   geometry      `sample_image_grid`, `get_world_rays` (src/geometry/projection.py:117-138,91-114),
-                `absolute_to_relative_camera` (src/misc/camera_utils.py:7-25)  -- tiny host-side fp32
-                torch algebra, once per `sample()` ("host-side is fine")
+                `absolute_to_relative_camera` (src/misc/camera_utils.py:7-25): the reference's host-side
+                functions on 4x4 / 3x3 camera matrices, kept as the readable specification
+                (`ray_encode_host`); the per-pixel ray grid the sampler consumes is evaluated by the HIP
+                kernel `mvldm_ray_encode` (`ray_encode`), straight into the UNet input buffer
   MVLDMPipeline `first_stage_encode` (:278-287), `last_stage_decode` (:289-298), `ray_encode`
                 (:301-322), `step` (:413-453), `sample` (:455-490)
 
@@ -59,9 +61,19 @@ def absolute_to_relative_camera(tform, index: int):
     return torch.linalg.inv(ref) @ tform
 
 
-def ray_encode(ctx_extr, ctx_intr, tgt_extr, tgt_intr, hl: int, wl: int):
-    """[b, v_c+v_t, 6, hl, wl]: ray origins then directions (raw; `use_ray_encoding`,
-    `srt_ray_encoding`, `use_plucker` all off in the released config).  diffusion_wrapper.py:169-190,301-322"""
+def ray_encode(ctx_extr, ctx_intr, tgt_extr, tgt_intr, hl: int, wl: int, device=None):
+    """[b, v_c+v_t, 6, hl, wl] fp32 on the GPU: ray origins then directions (raw; `use_ray_encoding`,
+    `srt_ray_encoding`, `use_plucker` all off in the released config) by the HIP kernel.
+    diffusion_wrapper.py:169-190,301-322"""
+    dev = torch.device(device) if device is not None else (ctx_extr.device if ctx_extr.is_cuda else torch.device("cuda"))
+    extr = torch.cat([ctx_extr, tgt_extr], dim=1).to(dev, torch.float32).contiguous()
+    intr = torch.cat([ctx_intr, tgt_intr], dim=1).to(dev, torch.float32).contiguous()
+    b, v = extr.shape[:2]
+    return ops.ray_encode(extr.view(b * v, 4, 4), intr.view(b * v, 3, 3), hl, wl).view(b, v, 6, hl, wl)
+
+
+def ray_encode_host(ctx_extr, ctx_intr, tgt_extr, tgt_intr, hl: int, wl: int):
+    """the same tensor by the reference's own host functions (specification; CPU tests pin it to G3)"""
     def rays(extr, intr):
         xy, _ = sample_image_grid((hl, wl), device=extr.device, dtype=extr.dtype)
         return get_world_rays(xy.reshape(hl * wl, 2), extr[:, :, None], intr[:, :, None])
@@ -88,6 +100,10 @@ class MVLDMPipeline:
         self._plans = {}
 
     @property
+    def latent_downscale(self) -> int:
+        return 2 ** (len(self.autoencoder.config.block_out_channels) - 1)
+
+    @property
     def device(self):
         return next(self.denoiser.parameters()).device
 
@@ -96,17 +112,19 @@ class MVLDMPipeline:
 
     # ---- VAE wrappers (diffusion_wrapper.py:278-298) -----------------------------------------------
     def first_stage_encode(self, images, noise=None, generator=None):
+        """`inputs * 2 - 1` rides in the encoder plan's layout kernel, `latent_dist.sample() * 0.18215` is one HIP kernel"""
         b, v = images.shape[:2]
-        x = (images.reshape(b * v, *images.shape[2:]).to(self.device, torch.float32) * 2.0 - 1.0).contiguous()
-        z = self.autoencoder.encode(x).latent_dist.sample(generator=generator, noise=noise) * VAE_SCALE
+        x = images.reshape(b * v, *images.shape[2:]).to(self.device, torch.float32).contiguous()
+        z = self.autoencoder.encode(x, pre_scale=2.0, pre_shift=-1.0).latent_dist.sample(generator=generator, noise=noise,
+                                                                                         scale=VAE_SCALE)
         return z.reshape(b, v, *z.shape[1:])
 
     def last_stage_decode(self, latents):
+        """`(1 / 0.18215) * latents` and `(image / 2 + 0.5).clamp(0, 1)` ride in the decoder plan's layout kernels"""
         b, v = latents.shape[:2]
-        z = ((1 / VAE_SCALE) * latents.reshape(b * v, *latents.shape[2:]).to(self.device, torch.float32)).contiguous()
-        img = self.autoencoder.decode(z).sample
-        img = img.reshape(b, v, *img.shape[1:])
-        return (img / 2 + 0.5).clamp(0, 1)
+        z = latents.reshape(b * v, *latents.shape[2:]).to(self.device, torch.float32).contiguous()
+        img = self.autoencoder.decode(z, pre_scale=1 / VAE_SCALE, post_scale=0.5, post_shift=0.5, clamp01=True).sample
+        return img.reshape(b, v, *img.shape[1:])
 
     # ---- the reference's step, literally (diffusion_wrapper.py:413-453) ----------------------------
     def step(self, model, x_t, ts, context_inputs, ray_encodings, target_mask):
@@ -132,14 +150,16 @@ class MVLDMPipeline:
         zero = torch.zeros(1, dtype=torch.int32, device=dev)
         eps = torch.stack([pred_c.float().reshape(-1), pred_u.float().reshape(-1)]).view(2, 1, -1, 1).contiguous()
         out = ops.ddim_cfg_step(eps, x_t.float().contiguous().view(1, 1, -1, 1), zero, torch.ones(1, dtype=torch.int32, device=dev),
-                                self.cfg.cfg_scale, coef, zero, None)
+                                self.cfg.cfg_scale, coef, zero, None, clip_range=self.scheduler.clip_range)
         return out.view(x_t.shape)
 
     # ---- production sampler ------------------------------------------------------------------------
     def _compile(self, b: int, v_c: int, v_t: int, hl: int, wl: int, dtype, n_steps: int):
-        key = (b, v_c, v_t, hl, wl, dtype, n_steps, self.cfg.use_cfg, self.cfg.cfg_scale, str(self.device))
+        sch = self.scheduler
+        key = (b, v_c, v_t, hl, wl, dtype, n_steps, self.cfg.use_cfg, self.cfg.cfg_scale, str(self.device),
+               tuple(int(t) for t in sch.timesteps), sch.clip_range)
         st = self._plans.get(key)
-        if st is not None:
+        if st is not None and st["weights_version"] == self.denoiser.weights_version():
             return st
         dev, den = self.device, self.denoiser
         lc = den.out_channels
@@ -157,7 +177,6 @@ class MVLDMPipeline:
         unc_img = (torch.tensor([n_cond + s * v_t + j for s in range(b) for j in range(v_t)], dtype=torch.int32, device=dev)
                    if use_cfg else None)
         tgt_rows = cond_img if not use_cfg else torch.cat([cond_img, unc_img])
-        sch = self.scheduler
         t_table = sch.timesteps.to(dev, torch.int64).contiguous()
         coef = sch.coefficient_table().to(dev)
         step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -165,52 +184,71 @@ class MVLDMPipeline:
         bld = Builder(dev, dtype, record=True)
         with bld.scope("unet"):
             den.emit(bld, unet_in, timesteps, groups, out=eps)
-        bld.ddim_step(eps, x_state, x_state, cond_img, unc_img, self.cfg.cfg_scale, coef, step_ptr, unet_in)
+        bld.ddim_step(eps, x_state, x_state, cond_img, unc_img, self.cfg.cfg_scale, coef, step_ptr, unet_in,
+                      clip_range=sch.clip_range)
         bld.ddim_advance(step_ptr, t_table, timesteps, tgt_rows)
         plan = bld.finalize()
         plan.capture()
-        st = dict(plan=plan, unet_in=unet_in, x_state=x_state, eps=eps, timesteps=timesteps, cond_img=cond_img,
-                  unc_img=unc_img, tgt_rows=tgt_rows, t_table=t_table, step_ptr=step_ptr, n_cond=n_cond)
+        # ---- loader plan: everything `sample()` writes before the DDIM loop (diffusion_wrapper.py:476-481, 429-432):
+        # [latent 0..3 | mask 4 | rays 5..10] of every UNet input row, the fp32 DDIM state, step counter / timesteps.
+        # Padding channels, context-view masks and context-view timesteps are zero from the allocation above.
+        ctx_lat = torch.zeros(b * v_c, lc, hl, wl, dtype=torch.float32, device=dev)
+        x_T = torch.zeros(b * v_t, lc, hl, wl, dtype=torch.float32, device=dev)
+        ones = torch.ones(b * v_t, 1, hl, wl, dtype=torch.float32, device=dev)
+        extr = torch.zeros(n_img, 4, 4, dtype=torch.float32, device=dev)
+        intr = torch.zeros(n_img, 3, 3, dtype=torch.float32, device=dev)
+        ctx_rows = torch.tensor([s * v + j for s in range(b) for j in range(v_c)], dtype=torch.int32, device=dev)
+        minus_one = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        ld = Builder(dev, dtype, record=True)
+        ld.memcpy(step_ptr, minus_one, name="step_ptr=-1")
+        ld.ddim_advance(step_ptr, t_table, timesteps, tgt_rows, name="step 0 / timesteps[targets] = t_0")
+        ld.nchw_to_nhwc(ctx_lat, unet_in, 0, img_map=ctx_rows, name="context latents")
+        for rows in ((cond_img, unc_img) if use_cfg else (cond_img,)):
+            ld.nchw_to_nhwc(x_T, unet_in, 0, img_map=rows, name="x_T")
+            ld.nchw_to_nhwc(ones, unet_in, lc, img_map=rows, name="target mask")
+        ld.ray_encode(extr, intr, hl, wl, unet_in, lc + 1, name="ray grid")
+        ld.nchw_to_nhwc(x_T, x_state, 0, name="x_T -> fp32 state")
+        loader = ld.finalize(autotune=False)
+        st = dict(plan=plan, loader=loader, unet_in=unet_in, x_state=x_state, eps=eps, timesteps=timesteps, cond_img=cond_img,
+                  unc_img=unc_img, tgt_rows=tgt_rows, t_table=t_table, step_ptr=step_ptr, n_cond=n_cond,
+                  ctx_lat=ctx_lat, x_T=x_T, extr=extr, intr=intr, weights_version=den.weights_version())
         self._plans[key] = st
         return st
 
-    def load_inputs(self, st, ctx_latents, x_T, rays, v_c: int):
-        """write the per-sample constants into the UNet input buffer: [latent 0..3 | mask 4 | rays 5..10]
-        (diffusion_wrapper.py:429-432,476-481); context views are clean (mask 0, timestep 0)."""
-        dev, ui = self.device, st["unet_in"]
+    def load_inputs(self, st, ctx_latents, x_T, ctx_cams, tgt_cams):
+        """stage the per-sample inputs (context latents [b,v_c,c,h,w], x_T [b,v_t,c,h,w], cameras = (extrinsics
+        [b,v,4,4], intrinsics [b,v,3,3])) into the plan's fixed buffers -- copies only -- and run the loader plan
+        (HIP layout / ray kernels) that assembles the UNet input and re-arms the step counter."""
         b, v_t = x_T.shape[:2]
-        v = v_c + v_t
-        lc = x_T.shape[2]
-        dtype = ui.dtype
-        nhwc = lambda t: t.to(dev, torch.float32).permute(0, 1, 3, 4, 2)        # [b, v, h, w, c]
-        ui.zero_()
-        cond = ui[:st["n_cond"]].view(b, v, *ui.shape[1:])
-        cond[:, :v_c, ..., :lc] = nhwc(ctx_latents).to(dtype)
-        cond[:, v_c:, ..., :lc] = nhwc(x_T).to(dtype)
-        cond[:, v_c:, ..., lc] = 1.0
-        cond[..., lc + 1:lc + 7] = nhwc(rays).to(dtype)
-        if st["unc_img"] is not None:
-            unc = ui[st["n_cond"]:].view(b, v_t, *ui.shape[1:])
-            unc[..., :lc] = nhwc(x_T).to(dtype)
-            unc[..., lc] = 1.0
-            unc[..., lc + 1:lc + 7] = nhwc(rays[:, v_c:]).to(dtype)
-        st["x_state"].copy_(nhwc(x_T).reshape(st["x_state"].shape))
-        st["step_ptr"].zero_()
-        st["timesteps"].zero_()
-        st["timesteps"][st["tgt_rows"].long()] = st["t_table"][0]
+        st["ctx_lat"].copy_(ctx_latents.reshape(st["ctx_lat"].shape))
+        st["x_T"].copy_(x_T.reshape(st["x_T"].shape))
+        n_cond = st["n_cond"]
+        for buf, ci, ti, k in ((st["extr"], ctx_cams[0], tgt_cams[0], 4), (st["intr"], ctx_cams[1], tgt_cams[1], 3)):
+            allc = torch.cat([ci.reshape(b, -1, k, k), ti.reshape(b, -1, k, k)], dim=1).to(torch.float32)
+            buf[:n_cond].copy_(allc.reshape(n_cond, k, k))
+            if st["unc_img"] is not None:
+                buf[n_cond:].copy_(ti.reshape(b * v_t, k, k))
+        st["loader"].run()
 
-    def denoise(self, ctx_latents, x_T, rays, dtype=None):
-        """the DDIM loop of `sample()` on latents: returns x_0 [b, v_t, c, hl, wl] fp32"""
+    def _scaled_noise(self, x_T):
+        sigma = self.scheduler.init_noise_sigma        # 1.0 for DDIM (diffusion_wrapper.py:474)
+        return x_T if sigma == 1.0 else x_T * sigma
+
+    def _read_state(self, st, b, v_t):
+        hl, wl, lc = st["x_state"].shape[1:]
+        return ops.nhwc_to_nchw(st["x_state"]).view(b, v_t, lc, hl, wl)
+
+    def denoise(self, ctx_latents, x_T, ctx_cams, tgt_cams, dtype=None):
+        """the DDIM loop of `sample()` on latents: returns x_0 [b, v_t, c, hl, wl] fp32.  `*_cams` = (extrinsics, intrinsics)"""
         dtype = dtype or get_compute_dtype()
         b, v_c = ctx_latents.shape[:2]
         v_t, hl, wl = x_T.shape[1], x_T.shape[3], x_T.shape[4]
         n_steps = len(self.scheduler.timesteps)
         st = self._compile(b, v_c, v_t, hl, wl, dtype, n_steps)
-        self.load_inputs(st, ctx_latents, x_T * self.scheduler.init_noise_sigma, rays, v_c)
+        self.load_inputs(st, ctx_latents, self._scaled_noise(x_T), ctx_cams, tgt_cams)
         for _ in range(n_steps):
             st["plan"].replay()
-        x0 = st["x_state"].view(b, v_t, hl, wl, -1).permute(0, 1, 4, 2, 3).contiguous()
-        return x0
+        return self._read_state(st, b, v_t)
 
     def prepare(self, batch, x_T=None, encode_noise=None, dtype=None):
         """everything of `sample()` before the DDIM loop: encode the context views, draw x_T, evaluate the ray
@@ -222,12 +260,9 @@ class MVLDMPipeline:
         v_t = tgt["extrinsics"].shape[1]
         if x_T is None:
             x_T = torch.randn((b, v_t, c, hl, wl))
-        # (cameras are a few hundred floats: the per-pixel ray grid is evaluated where the latents live)
-        dev = self.device
-        cam = lambda t: t.to(dev, torch.float32)
-        rays = ray_encode(cam(ctx["extrinsics"]), cam(ctx["intrinsics"]), cam(tgt["extrinsics"]), cam(tgt["intrinsics"]), hl, wl)
         st = self._compile(b, v_c, v_t, hl, wl, dtype, len(self.scheduler.timesteps))
-        self.load_inputs(st, ctx_lat, x_T.to(dev) * self.scheduler.init_noise_sigma, rays, v_c)
+        self.load_inputs(st, ctx_lat, self._scaled_noise(x_T), (ctx["extrinsics"], ctx["intrinsics"]),
+                         (tgt["extrinsics"], tgt["intrinsics"]))
         return st
 
     def sample(self, batch, x_T=None, encode_noise=None, decode: bool = True, dtype=None):
@@ -239,6 +274,5 @@ class MVLDMPipeline:
             st["plan"].replay()
         b = batch["context"]["image"].shape[0]
         v_t = batch["target"]["extrinsics"].shape[1]
-        hl, wl = st["x_state"].shape[1:3]
-        x0 = st["x_state"].view(b, v_t, hl, wl, -1).permute(0, 1, 4, 2, 3).contiguous()
+        x0 = self._read_state(st, b, v_t)
         return (self.last_stage_decode(x0) if decode else None), x0

@@ -251,7 +251,8 @@ class Builder:
         self._emit(op, name, 0.0, x.numel() * (x.element_size() + y.element_size()), (x, y))
         return y
 
-    def ddim_step(self, eps, x_t, x_next, cond_img, uncond_img, cfg_scale, coef, step_ptr, unet_in, name="ddim_cfg_step"):
+    def ddim_step(self, eps, x_t, x_next, cond_img, uncond_img, cfg_scale, coef, step_ptr, unet_in, name="ddim_cfg_step",
+                  clip_range: float = 0.0):
         n_tgt, h, w, c = x_t.shape
         op = L.Op()
         op.kind = L.OP_DDIM_STEP
@@ -261,6 +262,7 @@ class Builder:
         d.n_tgt, d.hw, d.c, d.cfg_scale = n_tgt, h * w, c, cfg_scale
         d.unet_in_c = 0 if unet_in is None else unet_in.shape[-1]
         d.unet_in_dtype = L.F32 if unet_in is None else dt(unet_in)
+        d.n_steps, d.clip_range = coef.shape[0], clip_range
         self._emit(op, name, 0.0, 5.0 * x_t.numel() * 4, (eps, x_t, x_next, cond_img, uncond_img, coef, step_ptr, unet_in))
         return x_next
 
@@ -289,14 +291,34 @@ class Builder:
         self._emit(op, name, 0.0, src.numel() * src.element_size() + dst.numel() * 4, (src, dst))
         return dst
 
-    def nchw_to_nhwc(self, src, dst, c_off=0, name="nchw_to_nhwc"):
+    def nchw_to_nhwc(self, src, dst, c_off=0, scale=1.0, shift=0.0, img_map=None, name="nchw_to_nhwc"):
         n, c, h, w = src.shape
         op = L.Op()
         op.kind = L.OP_NCHW_TO_NHWC
         l = op.u.layout
         l.src, l.dst, l.n_img, l.c, l.hw, l.other_c, l.other_c_off, l.dtype = ptr(src), ptr(dst), n, c, h * w, dst.shape[-1], c_off, dt(dst)
-        self._emit(op, name, 0.0, src.numel() * 4 + dst.numel() * dst.element_size(), (src, dst))
+        l.scale, l.shift, l.img_map = scale, shift, ptr(img_map)
+        self._emit(op, name, 0.0, src.numel() * 4 + src.numel() * dst.element_size(), (src, dst, img_map))
         return dst
+
+    def ray_encode(self, extr, intr, h, w, out_nhwc, c_off, img_map=None, out_nchw=None, name="ray_encode"):
+        """extr fp32 [n,4,4], intr fp32 [n,3,3] device buffers (filled by the caller before each run)"""
+        op = L.Op()
+        op.kind = L.OP_RAY_ENCODE
+        r = op.u.rays
+        r.extrinsics, r.intrinsics, r.out_nchw, r.out_nhwc, r.img_map = ptr(extr), ptr(intr), ptr(out_nchw), ptr(out_nhwc), ptr(img_map)
+        r.n_cam, r.h, r.w = extr.shape[0], h, w
+        r.nhwc_c, r.nhwc_c_off, r.nhwc_dtype = (0, 0, L.F32) if out_nhwc is None else (out_nhwc.shape[-1], c_off, dt(out_nhwc))
+        self._emit(op, name, 0.0, extr.shape[0] * h * w * 6 * 4.0, (extr, intr, out_nhwc, out_nchw, img_map))
+
+    def posterior_sample(self, moments, noise, out, scale=1.0, name="posterior_sample"):
+        n, c2, h, w = moments.shape
+        op = L.Op()
+        op.kind = L.OP_POSTERIOR_SAMPLE
+        q = op.u.posterior
+        q.moments, q.noise, q.out, q.n, q.c, q.hw, q.scale = ptr(moments), ptr(noise), ptr(out), n, c2 // 2, h * w, scale
+        self._emit(op, name, 0.0, moments.numel() * 4 * 2.0, (moments, noise, out))
+        return out
 
     # ---- finish ---------------------------------------------------------------------------------
     def finalize(self, autotune: Optional[bool] = None) -> "Plan":

@@ -38,15 +38,16 @@ class SchedulerCfg:
     """src/model/scheduler/__init__.py:11-17"""
     name: str = "ddim"
     num_train_timesteps: int = 1000
-    num_inference_steps: int = 50
+    num_inference_steps: int = 70       # config/model/scheduler/ddim.yaml, config/experiment/baseline.yaml:36
     pretrained_from: Optional[str] = None
-    kwargs: DDIMSchedulerCfg = None
+    kwargs: Optional[DDIMSchedulerCfg] = None
 
 
 class DDIMScheduler:
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
                  beta_schedule: str = "linear", trained_betas=None, clip_sample: bool = True, set_alpha_to_one: bool = True,
-                 steps_offset: int = 0, prediction_type: str = "epsilon", timestep_spacing: str = "leading"):
+                 steps_offset: int = 0, prediction_type: str = "epsilon", timestep_spacing: str = "leading",
+                 clip_sample_range: float = 1.0):
         if trained_betas is not None:
             self.betas = torch.tensor(np.asarray(trained_betas), dtype=torch.float32)
         elif beta_schedule == "linear":
@@ -57,9 +58,11 @@ class DDIMScheduler:
             raise NotImplementedError(f"beta_schedule {beta_schedule}")
         if prediction_type != "epsilon" or timestep_spacing != "leading":
             raise NotImplementedError("only epsilon prediction with leading spacing is on the reference's path")
-        if clip_sample:
-            raise NotImplementedError("clip_sample=True: the released config sets clip_sample False (config/model/scheduler/ddim.yaml:9)")
+        # diffusers' default `clip_sample=True` clamps the predicted x0 to +-clip_sample_range inside the fused kernel
+        # (the released config sets it False, config/model/scheduler/ddim.yaml:9)
+        self.clip_range = float(clip_sample_range) if clip_sample else 0.0
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, clip_sample=clip_sample,
+                                      clip_sample_range=clip_sample_range,
                                       steps_offset=steps_offset, prediction_type=prediction_type,
                                       set_alpha_to_one=set_alpha_to_one)
         self.alphas = 1.0 - self.betas
@@ -69,6 +72,22 @@ class DDIMScheduler:
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
         self._dev = {}
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder: str = "scheduler"):
+        """`SCHEDULER[name].from_pretrained(path, subfolder="scheduler")` (src/model/scheduler/__init__.py:37): reads
+        `<path>/<subfolder>/scheduler_config.json` from a LOCAL diffusers snapshot (no hub access offline)."""
+        import inspect
+        import json
+        import os
+        f = os.path.join(str(path), subfolder, "scheduler_config.json")
+        if not os.path.isfile(f):
+            raise FileNotFoundError(f"{f}: scheduler.from_pretrained needs a local diffusers snapshot (no hub access); "
+                                    "or pass kwargs like the released config (config/model/scheduler/ddim.yaml)")
+        with open(f) as fh:
+            cfg = json.load(fh)
+        ok = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        return cls(**{k: v for k, v in cfg.items() if k in ok})
 
     # ---- host-side tables ------------------------------------------------------------------------
     def set_timesteps(self, num_inference_steps: int, device=None):
@@ -110,7 +129,7 @@ class DDIMScheduler:
         x = sample.float().contiguous().view(1, 1, -1, 1)
         e = model_output.float().contiguous().view(1, 1, -1, 1)
         idx = self._dev.setdefault(("idx", str(dev)), torch.zeros(1, dtype=torch.int32, device=dev))
-        out = ops.ddim_cfg_step(e, x, idx, None, 0.0, coef, step0, None)
+        out = ops.ddim_cfg_step(e, x, idx, None, 0.0, coef, step0, None, clip_range=self.clip_range)
         return SimpleNamespace(prev_sample=out.view(sample.shape))
 
     def add_noise(self, original_samples, noise, timesteps):
@@ -125,13 +144,24 @@ class DDIMScheduler:
         return sa * original_samples + so * noise
 
 
-SCHEDULER = {"ddim": DDIMScheduler}
+class DDPMScheduler(DDIMScheduler):
+    """`SCHEDULER["ddpm"]` (src/model/scheduler/__init__.py:19-22).  The reference only ever STEPS the DDIM scheduler
+    (config/model/scheduler/ddim.yaml; SURVEY.md §2 #6 marks DDPM stepping out of scope); what training uses of either
+    class -- the beta tables and `add_noise` (diffusion_wrapper.py:370) -- is identical and inherited.  Ancestral
+    sampling (`step`) needs the posterior variance and fresh noise per step: not on the path, refused loudly."""
+
+    def step(self, *a, **kw):
+        raise NotImplementedError("DDPMScheduler.step (ancestral sampling) is not on the reference's released path; "
+                                  "use the DDIM scheduler for sampling")
+
+
+SCHEDULER = {"ddim": DDIMScheduler, "ddpm": DDPMScheduler}
 
 
 def get_scheduler(cfg: SchedulerCfg) -> DDIMScheduler:
     """src/model/scheduler/__init__.py:30-40"""
     if cfg.pretrained_from is not None:
-        raise NotImplementedError("scheduler.from_pretrained needs hub access; pass kwargs (the reference's released "
-                                  "config does, config/model/scheduler/ddim.yaml)")
-    kw = asdict(cfg.kwargs) if cfg.kwargs is not None else {}
+        return SCHEDULER[cfg.name].from_pretrained(cfg.pretrained_from, subfolder="scheduler")
+    kw = cfg.kwargs if cfg.kwargs is not None else {}
+    kw = asdict(kw) if hasattr(kw, "__dataclass_fields__") else dict(kw)
     return SCHEDULER[cfg.name](**kw)

@@ -18,7 +18,9 @@ import torch
 from torch import nn
 
 from . import ops
-from .modules import Builder, Conv2d, Downsample2D, GroupNorm, ResnetBlock2D, UNetMidBlock2D, Upsample2D
+import warnings
+
+from .modules import Builder, Conv2d, Downsample2D, GroupNorm, ResnetBlock2D, UNetMidBlock2D, Upsample2D, weights_version
 from .runtime import get_compute_dtype, require_gpu
 
 SD21_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
@@ -119,18 +121,28 @@ class Decoder(nn.Module):
 
 
 class DiagonalGaussianDistribution:
-    """mean/logvar split, logvar clamp, reparameterised sample (tiny [N,4,h,w] tensors: torch
-    elementwise on the device -- RNG is the caller's, SURVEY.md §7 'RNG placement')."""
+    """diffusers `DiagonalGaussianDistribution` over the encoder's `moments` ([N, 2c, h, w] fp32 = mean | logvar).
+    `sample()` is the HIP kernel `mvldm_posterior_sample` (clamp, exp, reparameterisation, optional scale); the RNG is
+    the caller's (SURVEY.md §7 'RNG placement').  `.mean` / `.logvar` / `.std` are views / lazily evaluated accessors
+    for inspection (tests), not used on the sampling path."""
 
     def __init__(self, parameters: torch.Tensor):
-        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
-        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
-        self.std = torch.exp(0.5 * self.logvar)
+        self.parameters = parameters
+        self.mean, self._raw_logvar = torch.chunk(parameters, 2, dim=1)
 
-    def sample(self, generator=None, noise=None):
+    @property
+    def logvar(self):
+        return torch.clamp(self._raw_logvar, -30.0, 20.0)
+
+    @property
+    def std(self):
+        return torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None, noise=None, scale: float = 1.0):
         if noise is None:
-            noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
-        return self.mean + self.std * noise.to(self.mean.device, self.mean.dtype)
+            noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=torch.float32)
+        noise = noise.to(self.mean.device, torch.float32).contiguous()
+        return ops.posterior_sample(self.parameters.contiguous(), noise, scale)
 
     def mode(self):
         return self.mean
@@ -150,21 +162,34 @@ class AutoencoderKL(nn.Module):
         self._plans = {}
 
     @classmethod
-    def from_pretrained(cls, path, subfolder="vae", config_overrides=None, state_dict=None):
+    def from_pretrained(cls, path, subfolder="vae", config_overrides=None, state_dict=None, allow_random_init=False):
+        """SD-2.1 VAE topology.  Weights: `state_dict` (diffusers key layout), or a LOCAL snapshot / checkpoint file at
+        `path` (`<path>/<subfolder>/diffusion_pytorch_model.safetensors|.bin`, or a .safetensors/.ckpt file); there is no
+        hub access offline, so anything else leaves torch's random init -- with a warning unless `allow_random_init`."""
         cfg = dict(SD21_VAE_CONFIG)
         cfg.update(config_overrides or {})
         m = cls(**cfg)
         if state_dict is not None:
             m.load_state_dict(state_dict)
+            return m
+        from .checkpoint import find_local_weights, load_vae_checkpoint
+        f = find_local_weights(path, subfolder)
+        if f is not None:
+            load_vae_checkpoint(m, f)
+        elif not allow_random_init:
+            warnings.warn(f"AutoencoderKL.from_pretrained({path!r}): no local weights found and no state_dict given -- the "
+                          "module keeps RANDOM initial weights (pass allow_random_init=True to silence)", stacklevel=2)
         return m
 
     # ---- plans -----------------------------------------------------------------------------------
-    def _compile(self, kind: str, n: int, h: int, w: int, dtype):
+    def _compile(self, kind: str, n: int, h: int, w: int, dtype, io=(1.0, 0.0, 1.0, 0.0, False)):
+        """`io` = (pre_scale, pre_shift, post_scale, post_shift, clamp01): affine maps folded into the plan's layout kernels"""
         dev = next(self.parameters()).device
-        key = (kind, n, h, w, dtype, str(dev))
+        key = (kind, n, h, w, dtype, str(dev), io)
         st = self._plans.get(key)
-        if st is not None:
+        if st is not None and st["weights_version"] == weights_version(self):
             return st
+        pre_scale, pre_shift, post_scale, post_shift, clamp01 = io
         e = ops.epc(dtype)
         lc = self.config.latent_channels
         bld = Builder(dev, dtype, record=True)
@@ -172,7 +197,7 @@ class AutoencoderKL(nn.Module):
             c_pad = (lc + e - 1) // e * e
             src = torch.zeros(n, lc, h, w, dtype=torch.float32, device=dev)
             z = torch.zeros(n, h, w, c_pad, dtype=dtype, device=dev)
-            bld.nchw_to_nhwc(src, z)
+            bld.nchw_to_nhwc(src, z, scale=pre_scale, shift=pre_shift)
             pq = self.post_quant_conv
             # the 1x1 post_quant conv writes its `latent_channels` columns into a zeroed c_pad-wide NHWC
             # buffer (dst_ld = c_pad) so that decoder.conv_in reads whole 16-byte chunks
@@ -180,20 +205,20 @@ class AutoencoderKL(nn.Module):
             bld.conv(z, pq.packed(dtype, c_pad), pq._f32("bias"), out=z2, name="post_quant_conv")
             y = self.decoder.emit(bld, z2)
             out = torch.zeros(n, self.config.out_channels, y.shape[1], y.shape[2], dtype=torch.float32, device=dev)
-            bld.nhwc_to_nchw(y, out)
+            bld.nhwc_to_nchw(y, out, scale=post_scale, shift=post_shift, clamp01=clamp01)
         else:
             ic = self.config.in_channels
             c_pad = (ic + e - 1) // e * e
             src = torch.zeros(n, ic, h, w, dtype=torch.float32, device=dev)
             x = torch.zeros(n, h, w, c_pad, dtype=dtype, device=dev)
-            bld.nchw_to_nhwc(src, x)
+            bld.nchw_to_nhwc(src, x, scale=pre_scale, shift=pre_shift)
             hh = self.encoder.emit(bld, x)
             qc = self.quant_conv
             m = bld.conv(hh, qc.packed(dtype, hh.shape[-1]), qc._f32("bias"), out_dtype=torch.float32, name="quant_conv")
             out = torch.zeros(n, 2 * lc, m.shape[1], m.shape[2], dtype=torch.float32, device=dev)
             bld.nhwc_to_nchw(m, out)
         plan = bld.finalize()
-        st = dict(plan=plan, src=src, out=out)
+        st = dict(plan=plan, src=src, out=out, weights_version=weights_version(self))
         self._plans[key] = st
         return st
 
@@ -217,26 +242,32 @@ class AutoencoderKL(nn.Module):
             out.append(n % size)
         return out
 
-    def decode(self, z: torch.Tensor, dtype=None):
+    def decode(self, z: torch.Tensor, dtype=None, pre_scale: float = 1.0, post_scale: float = 1.0, post_shift: float = 0.0,
+               clamp01: bool = False):
+        """diffusers `decode(z).sample`; the optional affine maps (`z * pre_scale`, `img * post_scale + post_shift`,
+        clamp to [0,1]) ride in the boundary layout kernels (last_stage_decode, diffusion_wrapper.py:289-298)"""
         require_gpu(z)
         n, c, h, w = z.shape
         dtype = dtype or get_compute_dtype()
         outs, i0 = [], 0
-        for m in self._chunks(n, 8 * h, 8 * w, dtype):
-            st = self._compile("decode", m, h, w, dtype)
+        up = 2 ** (len(self.config.block_out_channels) - 1)
+        for m in self._chunks(n, up * h, up * w, dtype):
+            st = self._compile("decode", m, h, w, dtype, (pre_scale, 0.0, post_scale, post_shift, bool(clamp01)))
             st["src"].copy_(z[i0:i0 + m])
             st["plan"].run()
             outs.append(st["out"].clone())
             i0 += m
         return SimpleNamespace(sample=outs[0] if len(outs) == 1 else torch.cat(outs))
 
-    def encode(self, x: torch.Tensor, dtype=None):
+    def encode(self, x: torch.Tensor, dtype=None, pre_scale: float = 1.0, pre_shift: float = 0.0):
+        """diffusers `encode(x).latent_dist`; `x * pre_scale + pre_shift` rides in the boundary layout kernel
+        (first_stage_encode's `inputs * 2 - 1`, diffusion_wrapper.py:281)"""
         require_gpu(x)
         n, c, h, w = x.shape
         dtype = dtype or get_compute_dtype()
         outs, i0 = [], 0
         for m in self._chunks(n, h, w, dtype):
-            st = self._compile("encode", m, h, w, dtype)
+            st = self._compile("encode", m, h, w, dtype, (pre_scale, pre_shift, 1.0, 0.0, False))
             st["src"].copy_(x[i0:i0 + m])
             st["plan"].run()
             outs.append(st["out"].clone())
@@ -251,6 +282,8 @@ class AutoencoderCfg:
     pretrained_from: Optional[str] = "stabilityai/stable-diffusion-2-1"
     kwargs: Optional[object] = None
     pretrained_overrides: Optional[dict] = None   # not in the reference: reduced widths for tests
+    state_dict: Optional[dict] = None             # not in the reference: weights in diffusers layout (no hub access offline)
+    allow_random_init: bool = False
 
 
 AUTOENCODERS = {"kl": AutoencoderKL}
@@ -263,4 +296,6 @@ def get_autoencoder(cfg: AutoencoderCfg) -> AutoencoderKL:
         raise NotImplementedError("autoencoder from config: the reference's own branch is broken "
                                   "(autoencoder/__init__.py:28,40); use pretrained_from")
     return AUTOENCODERS[cfg.name].from_pretrained(cfg.pretrained_from, subfolder="vae",
-                                                  config_overrides=getattr(cfg, "pretrained_overrides", None))
+                                                  config_overrides=getattr(cfg, "pretrained_overrides", None),
+                                                  state_dict=getattr(cfg, "state_dict", None),
+                                                  allow_random_init=getattr(cfg, "allow_random_init", False))

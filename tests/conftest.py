@@ -16,6 +16,8 @@ for p in (str(ROOT), str(GOLDEN)):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # tests build random-init modules on purpose (no checkpoints offline): the product's "RANDOM initial weights" warning is noise here
+    config.addinivalue_line("filterwarnings", "ignore:.*RANDOM initial weights.*:UserWarning")
 
 
 def pytest_collection_modifyitems(config, items):

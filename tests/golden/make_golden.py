@@ -203,11 +203,14 @@ def _ref_wrapper(use_cfg: bool, widths=(64, 128, 256, 256), vae_widths=(32, 64),
 
 def g5():
     out = {}
-    for ci, use_cfg in enumerate([False, True]):
+    # (use_cfg, b, v_c, v_t): cases 2, 3 are the (2 context + 3 target) calls that make up 25 of the 26 sample() calls of an
+    # anchored / autoregressive sequence (diffusion_wrapper.py:841-902, 961-1040), the second with two scenes per call
+    cases = [(False, 1, 1, 2), (True, 1, 1, 2), (True, 1, 2, 3), (True, 2, 2, 3)]
+    for ci, (use_cfg, b, v_c, v_t) in enumerate(cases):
         w = _ref_wrapper(use_cfg)
         cs_d = load_seeded(w.denoiser, 400)
         cs_v = load_seeded(w.autoencoder, 401)
-        b, v_c, v_t, H = 1, 1, 2, 32          # VAE widths (32,64): one downsample -> latents 16x16
+        H = 32                                # VAE widths (32,64): one downsample -> latents 16x16
         g = torch.Generator().manual_seed(5 + ci)
         ctx_img = torch.rand(b, v_c, 3, H, H, generator=g)
         extr, intr = random_cameras(b, v_c + v_t, seed=11 + ci)
@@ -217,7 +220,7 @@ def g5():
         batch = {"context": {"image": ctx_img, "extrinsics": extr[:, :v_c], "intrinsics": intr[:, :v_c]},
                  "target": {"image": torch.zeros(b, v_t, 3, H, H), "extrinsics": extr[:, v_c:],
                             "intrinsics": intr[:, v_c:]},
-                 "scene": ["synthetic"]}
+                 "scene": ["synthetic"] * b}
         w.set_timesteps(5)
         # the reference draws its noise from the global CPU generator (diffusion_wrapper.py:283,473):
         # feed it the recorded draws by patching randn for the duration of the call
@@ -249,8 +252,8 @@ def g5():
                     p + "ctx_img": ctx_img, p + "extr": extr, p + "intr": intr, p + "enc_noise": enc_noise,
                     p + "x_T": x_T, p + "img": img, p + "rays": rays, p + "step_ctx_lat": ctx_lat,
                     p + "step_x_t": x_t, p + "step_ts": int(w.scheduler.timesteps[1]), p + "step_x_prev": x_prev})
-        print(f"  g5 cfg={use_cfg}: img mean {img.mean():.4f}")
-    out["n"] = 2
+        print(f"  g5 cfg={use_cfg} b={b} v_c={v_c} v_t={v_t}: img mean {img.mean():.4f}")
+    out["n"] = len(cases)
     out["widths"] = np.array([64, 128, 256, 256])
     out["vae_widths"] = np.array([32, 64])
     save("g5_step_sample", **out)

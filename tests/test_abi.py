@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/mvldm.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.mvldm_abi_version() == 1
+    assert lib.mvldm_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define MVLDM_ABI_VERSION (\d+)', HEADER).group(1))
 
 
 def test_struct_layout_matches_header(tmp_path):

@@ -144,9 +144,9 @@ def test_step_and_sample_vs_reference_golden(M, golden, dtype):
             ctx_lat, x_t = torch.from_numpy(g[p + "step_ctx_lat"]).cuda(), torch.from_numpy(g[p + "step_x_t"]).cuda()
             hl = x_t.shape[-1]
             rays = ray_encode(extr[:, :v_c], intr[:, :v_c], extr[:, v_c:], intr[:, v_c:], hl, hl)
-            assert rel_err(rays, g[p + "rays"]) < 1e-6
+            assert rel_err(rays.cpu(), g[p + "rays"]) < 2e-6      # the HIP ray kernel (adjugate K^-1 in fp32) vs the reference
             ctx_in = torch.cat([ctx_lat, torch.zeros_like(ctx_lat[:, :, :1])], dim=2)
-            x_prev = pipe.step(pipe.denoiser, x_t, torch.tensor(int(g[p + "step_ts"])), ctx_in, rays.cuda(),
+            x_prev = pipe.step(pipe.denoiser, x_t, torch.tensor(int(g[p + "step_ts"])), ctx_in, rays,
                                torch.ones_like(x_t[:, :, :1]))
             e_step = rel_err(x_prev.cpu(), g[p + "step_x_prev"])
         assert e_step < TOL_MODEL[dtype], (ci, "step", e_step)

@@ -413,3 +413,62 @@ def test_upsample_conv_as_four_phase_convs(ops, dtype, n, c, cout, h, w, tile):
     close(nchw(y), ref, dtype, "phases")
     y_gather = ops.conv2d(nhwc(x, dtype), ops.pack_weight(wt.cuda(), dtype), b.cuda(), upsample=True)
     close(nchw(y), nchw(y_gather), dtype, "phases vs gather")
+
+
+def test_ddim_clip_sample_and_step_clamp_bit_exact(ops):
+    """diffusers' default `clip_sample=True` (x0 clamped to +-1 inside the fused kernel) against the oracle scheduler,
+    bit for bit; and a step counter beyond the table re-applies the LAST row instead of reading out of bounds"""
+    from oracle.scheduler import DDIMScheduler
+    s = DDIMScheduler(clip_sample=True)
+    s.set_timesteps(5)
+    from mv_ldm_amd.scheduler import DDIMScheduler as HS
+    h = HS()                                  # the mirrored defaults: clip_sample=True
+    h.set_timesteps(5)
+    assert h.clip_range == 1.0
+    g = G(61)
+    x, e = torch.randn(2, 3, 4, 8, 8, generator=g) * 2, torch.randn(2, 3, 4, 8, 8, generator=g)
+    for t in s.timesteps.tolist():
+        ref = s.step(e, torch.tensor(t), x).prev_sample
+        got = h.step(e.cuda(), t, x.cuda()).prev_sample
+        assert torch.equal(got.cpu(), ref), t
+    coef = h.coefficient_table().cuda()
+    xs, es = x.reshape(1, 1, -1, 1).cuda().contiguous(), e.reshape(1, 1, -1, 1).cuda().contiguous()
+    zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+    last = ops.ddim_cfg_step(es, xs, zero, None, 0.0, coef, torch.tensor([4], dtype=torch.int32, device="cuda"), None)
+    past = ops.ddim_cfg_step(es, xs, zero, None, 0.0, coef, torch.tensor([11], dtype=torch.int32, device="cuda"), None)
+    assert torch.equal(last, past) and torch.isfinite(past).all()
+
+
+def test_ray_grid_kernel_vs_reference_golden(ops, golden):
+    """mvldm_ray_encode against G3 (the reference's own get_world_rays / sample_image_grid outputs) and the NHWC slice form"""
+    g = golden("g3_rays")
+    extr, intr = torch.from_numpy(g["extrinsics"]).cuda(), torch.from_numpy(g["intrinsics"]).cuda()
+    b, v = extr.shape[:2]
+    for (h, w) in [(8, 8), (4, 6)]:
+        r = ops.ray_encode(extr.view(b * v, 4, 4), intr.view(b * v, 3, 3), h, w).view(b, v, 6, h * w).permute(0, 1, 3, 2).cpu()
+        o, d = torch.from_numpy(g[f"origins_{h}x{w}"]), torch.from_numpy(g[f"directions_{h}x{w}"])
+        assert (r[..., :3] - o).abs().max() == 0 and (r[..., 3:] - d).abs().max() < 5e-7, (h, w)
+    buf = torch.zeros(b * v + 2, 8, 8, 16, dtype=torch.bfloat16, device="cuda")
+    rows = torch.tensor([b * v + 1 - i for i in range(b * v)], dtype=torch.int32, device="cuda")      # reversed, offset by 2
+    ops.ray_encode(extr.view(b * v, 4, 4), intr.view(b * v, 3, 3), 8, 8, out_nhwc=buf, c_off=5, img_map=rows)
+    ref = ops.ray_encode(extr.view(b * v, 4, 4), intr.view(b * v, 3, 3), 8, 8)                          # [n, 6, 8, 8] fp32
+    assert torch.equal(buf[rows.long()][..., 5:11].cpu(), ref.permute(0, 2, 3, 1).to(torch.bfloat16).cpu())
+    assert float(buf[..., :5].abs().max()) == 0 and float(buf[..., 11:].abs().max()) == 0 and float(buf[:2].abs().max()) == 0
+
+
+def test_posterior_sample_and_mapped_layout(ops):
+    g = G(62)
+    mom = torch.randn(3, 8, 4, 4, generator=g) * 3
+    mom[0, 4:] = 40.0
+    mom[1, 4:] = -50.0                                   # exercise both clamps of logvar
+    noise = torch.randn(3, 4, 4, 4, generator=g)
+    ref = (mom[:, :4] + torch.exp(0.5 * mom[:, 4:].clamp(-30.0, 20.0)) * noise) * 0.18215
+    got = ops.posterior_sample(mom.cuda(), noise.cuda(), 0.18215).cpu()
+    assert ((got - ref).abs() <= 2e-6 * ref.abs() + 1e-30).all()
+    # nchw_to_nhwc with an affine map and a destination image map (the UNet input assembly)
+    img = torch.randn(3, 4, 4, 6, generator=g)
+    buf = torch.zeros(5, 4, 6, 8, dtype=torch.float16, device="cuda")
+    rows = torch.tensor([4, 0, 2], dtype=torch.int32, device="cuda")
+    ops.nchw_to_nhwc(img.cuda(), torch.float16, dst=buf, c_off=1, scale=2.0, shift=-1.0, img_map=rows)
+    assert torch.equal(buf[rows.long()][..., 1:5].cpu(), (img * 2.0 - 1.0).permute(0, 2, 3, 1).to(torch.float16))
+    assert float(buf[[1, 3]].abs().max()) == 0 and float(buf[..., 0].abs().max()) == 0 and float(buf[..., 5:].abs().max()) == 0

@@ -8,7 +8,7 @@ from conftest import rel_err
 
 
 def test_rays_and_relative_poses_vs_reference(golden):
-    from mv_ldm_amd.pipeline import absolute_to_relative_camera, get_world_rays, ray_encode, sample_image_grid
+    from mv_ldm_amd.pipeline import absolute_to_relative_camera, get_world_rays, ray_encode_host as ray_encode, sample_image_grid
     g = golden("g3_rays")
     extr, intr = torch.from_numpy(g["extrinsics"]), torch.from_numpy(g["intrinsics"])
     for (h, w) in [(8, 8), (4, 6)]:
@@ -41,8 +41,30 @@ def test_scheduler_tables_bit_exact(golden):
     assert float(tab[-1, 2]) == 1.0 and float(tab[-1, 3]) == 0.0          # final step: alpha_prev = 1 (set_alpha_to_one)
     x, e = torch.from_numpy(g["kat_x"]), torch.from_numpy(g["kat_eps"])
     assert np.array_equal(s.add_noise(x, e, torch.tensor([10, 900])).numpy(), g["kat_add_noise"])
+    # the mirrored dataclass defaults are usable as they are (diffusers' default clip_sample=True clamps x0 in the kernel)
+    d = get_scheduler(SchedulerCfg())
+    assert d.clip_range == 1.0 and DDIMScheduler(clip_sample=False).clip_range == 0.0 and SchedulerCfg().num_inference_steps == 70
+    from mv_ldm_amd.scheduler import SCHEDULER
+    assert set(SCHEDULER) == {"ddim", "ddpm"}                    # src/model/scheduler/__init__.py:19-22
+    p = SCHEDULER["ddpm"](clip_sample=False)
+    assert np.array_equal(p.add_noise(x, e, torch.tensor([10, 900])).numpy(), g["kat_add_noise"])
     with pytest.raises(NotImplementedError):
-        DDIMScheduler(clip_sample=True)
+        p.step(e, 10, x)
+
+
+def test_scheduler_from_pretrained_reads_a_local_snapshot(tmp_path):
+    """`SCHEDULER[name].from_pretrained(path, subfolder="scheduler")` (src/model/scheduler/__init__.py:37)"""
+    import json
+    from mv_ldm_amd.scheduler import DDIMScheduler, SchedulerCfg, get_scheduler
+    (tmp_path / "scheduler").mkdir()
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text(json.dumps(
+        {"_class_name": "DDIMScheduler", "beta_schedule": "scaled_linear", "beta_start": 0.00085, "beta_end": 0.012,
+         "clip_sample": False, "set_alpha_to_one": False, "steps_offset": 1, "num_train_timesteps": 1000, "skip_prk_steps": True}))
+    s = get_scheduler(SchedulerCfg(name="ddim", pretrained_from=str(tmp_path)))
+    assert isinstance(s, DDIMScheduler) and s.config.steps_offset == 1 and s.clip_range == 0.0
+    assert abs(float(s.betas[0]) - 0.00085) < 1e-9 and float(s.final_alpha_cumprod) == float(s.alphas_cumprod[0])
+    with pytest.raises(FileNotFoundError):
+        get_scheduler(SchedulerCfg(name="ddim", pretrained_from="stabilityai/stable-diffusion-2-1"))
 
 
 def test_no_cpu_fallback():

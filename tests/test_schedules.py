@@ -16,13 +16,20 @@ def _check(g, i):
     extr = torch.from_numpy(g[p + "abs_extr"])
     n_c = len(ctx_index)
     fn = anchored_schedule if mode == "anchored" else autoregressive_schedule
-    calls = fn(ctx_index, extr[:n_c], tgt_index, extr[n_c:], limit_frames=limit)
+    kw = {}
+    if mode == "anchored" and p + "num_anchors_views" in g.files:
+        kw["num_anchors_views"] = int(g[p + "num_anchors_views"])
+    calls = fn(ctx_index, extr[:n_c], tgt_index, extr[n_c:], limit_frames=limit, **kw)
+    prov = g[p + "calls_ctx_prov"]
     want_ctx, want_tgt, want_tag = g[p + "calls_ctx_idx"], g[p + "calls_tgt_idx"], g[p + "calls_ctx_tag"]
     assert len(calls) == want_ctx.shape[0], (mode, len(calls), want_ctx.shape[0])
     for k, c in enumerate(calls):
         assert c.ctx_index == [int(v) for v in want_ctx[k] if v >= 0], (k, c.ctx_index, want_ctx[k])
         assert c.tgt_index == [int(v) for v in want_tgt[k] if v >= 0], (k, c.tgt_index, want_tgt[k])
         assert c.ctx_source == [int(v) for v in want_tag[k] if v >= 0], (k, c.ctx_source, want_tag[k])
+        # provenance of every context image: 0 = original, else call * 8 + slot + 1 (make_golden_schedules.rec_sample)
+        got = [0 if src is None else src[0] * 8 + src[1] + 1 for src in c.ctx_from]
+        assert got == [int(v) for v in prov[k] if v >= 0], (k, got, prov[k])
         ce, te = g[p + "calls_ctx_extr"][k, :len(c.ctx_index)], g[p + "calls_tgt_extr"][k, :len(c.tgt_index)]
         assert np.abs(c.ctx_extrinsics.numpy() - ce).max() < 2e-6, (mode, k)
         assert np.abs(c.tgt_extrinsics.numpy() - te).max() < 2e-6, (mode, k)
@@ -46,3 +53,20 @@ def test_known_call_counts(golden):
     assert c0[0].tgt_index == [70, 139, 208, 277] and len(c0[0].ctx_index) == 1
     assert all(len(c.ctx_index) == 2 and len(c.tgt_index) == 3 for c in c0[1:])
     assert c1[0].tgt_index == [21, 41, 61]
+
+
+def test_chained_anchor_calls(golden):
+    """num_anchors_views = 7 / 10 (diffusion_wrapper.py:744-792): 1 + 1 (+1) anchor calls chained through the last
+    anchor, labels 4 anchors ahead of the poses, the frame generated twice; configurations the reference itself cannot
+    run are refused"""
+    import pytest
+    g = golden("g7_schedules")
+    c6, c7 = _check(g, 6), _check(g, 7)
+    assert len(c6[0].tgt_index) == 4 and len(c6[1].tgt_index) == 3 and c6[1].ctx_from[-1] == (0, 3)
+    assert c6[1].tgt_index[0] == c6[0].tgt_index[-1]              # the 4th anchor's label is generated again
+    assert len(c7[2].tgt_index) == 3 and c7[2].ctx_from[-1] == (1, 2)
+    extr = torch.eye(4).repeat(131, 1, 1)
+    with pytest.raises(ValueError):
+        anchored_schedule([0], extr[:1], list(range(1, 131)), extr[1:], num_anchors_views=10)
+    with pytest.raises(ValueError):
+        anchored_schedule([0], extr[:1], list(range(1, 101)), extr[1:], num_anchors_views=5)
