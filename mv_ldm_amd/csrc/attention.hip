@@ -31,6 +31,8 @@ struct AttnParams {
     float scale_log2e;
     int nqt;   // query tiles per (head, segment) in the 1-D grid of attention_kernel (set at launch)
     int remap; // 1: XCD-contiguous workgroup order (set at launch)
+    float* lse; // optional [heads][total q rows]: log2-domain log-sum-exp of the scaled scores (what the backward pass needs)
+    int lse_ld;
 };
 
 template <typename T> struct AttnMma;
@@ -318,6 +320,7 @@ void attention_kernel(const AttnParams p) {
     }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (!q_ok) return;
+    if (p.lse && hi == 0) p.lse[(size_t)head * p.lse_ld + q_row0 + q_local] = m_run * p.scale_log2e + __log2f(l_tot);   // P = exp2(s*c - lse)
     T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local) * p.ld_o + head * d;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -447,14 +450,15 @@ template <typename T, int DP> static int launch_attn(AttnParams p, int n_seg, in
 
 int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,
                   int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len, float scale, int dtype,
-                  hipStream_t s) {
+                  float* lse, int lse_ld, hipStream_t s) {
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(head_dim > 0 && head_dim % epc == 0, "attention: head_dim %d must be a multiple of %d", head_dim, epc);
     if (n_seg == 0 || max_q_len == 0) return MVLDM_OK;   // empty: buffers may be null
     MVLDM_REQUIRE(q && k && v && out && seg, "attention: null pointer");
     MVLDM_REQUIRE(ld_q % epc == 0 && ld_k % epc == 0 && ld_v % epc == 0 && ld_o % 4 == 0, "attention: row strides must keep 16-byte alignment");
     if (n_seg == 0 || max_q_len == 0) return MVLDM_OK;
-    AttnParams p{q, k, v, out, seg, ld_q, ld_k, ld_v, ld_o, heads, head_dim, scale * 1.4426950408889634f, 0, 0};
+    MVLDM_REQUIRE(!lse || head_dim <= 160, "attention: log-sum-exp output only on the MFMA kernels (head_dim <= 160)");
+    AttnParams p{q, k, v, out, seg, ld_q, ld_k, ld_v, ld_o, heads, head_dim, scale * 1.4426950408889634f, 0, 0, lse, lse_ld};
     const int dp = (head_dim + 15) / 16 * 16;
     return dispatch_dtype(dtype, [&](auto t) {
         using T = decltype(t);
@@ -479,7 +483,7 @@ int attention_run(const void* q, const void* k, const void* v, void* out, int ld
 
 extern "C" int mvldm_attention_fwd(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v,
                                    int ld_o, int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len,
-                                   float scale, int dtype, mvldm_stream_t stream) {
+                                   float scale, int dtype, float* lse, int lse_ld, mvldm_stream_t stream) {
     return mvldm::attention_run(q, k, v, out, ld_q, ld_k, ld_v, ld_o, heads, head_dim, seg, n_seg, max_q_len, scale,
-                                dtype, (hipStream_t)stream);
+                                dtype, lse, lse_ld, (hipStream_t)stream);
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
                                                        T* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const double* __restrict__ partial, int hw, int c, int groups,
-                                                       int rows_per_chunk, int nchunk, float eps, int silu) {
+                                                       int rows_per_chunk, int nchunk, float eps, int silu, float* __restrict__ stats_out) {
     constexpr int EPC = Elt<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_scale = reinterpret_cast<float*>(smem_raw);  // [c]
@@ -99,6 +99,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
         var = var > 0.0 ? var : 0.0;
         s_mean[tid] = (float)mean;
         s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        if (stats_out && chunk == 0) {       // (mean, rstd) per (image, group): what the backward pass needs
+            stats_out[((size_t)img * groups + tid) * 2] = s_mean[tid];
+            stats_out[((size_t)img * groups + tid) * 2 + 1] = s_rstd[tid];
+        }
     }
     __syncthreads();
     for (int ch = tid; ch < c; ch += blockDim.x) {
@@ -156,7 +160,7 @@ template <typename T, int KT>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0,
                                                         T* __restrict__ y, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int hw, int c, int groups, int span,
-                                                        float eps, int silu) {
+                                                        float eps, int silu, float* __restrict__ stats_out) {
     constexpr int EPC = Elt<T>::EPC;
     __shared__ double s_sum[64], s_sq[64];
     __shared__ float s_mean[64], s_rstd[64];
@@ -211,6 +215,10 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x0
         var = var > 0.0 ? var : 0.0;
         s_mean[tid] = (float)mean;
         s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        if (stats_out) {
+            stats_out[((size_t)img * groups + gbase + tid) * 2] = s_mean[tid];
+            stats_out[((size_t)img * groups + gbase + tid) * 2 + 1] = s_rstd[tid];
+        }
     }
     __syncthreads();
     float sc[EPC], sh[EPC];
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 }
 
 int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, const float* beta, int n_img, int hw, int c0,
-                  int c1, int groups, float eps, int silu, int dtype, void* stats_ws, hipStream_t s) {
+                  int c1, int groups, float eps, int silu, int dtype, void* stats_ws, float* stats_out, hipStream_t s) {
     MVLDM_REQUIRE(groups > 0 && groups <= 64 && (c0 + c1) % groups == 0, "groupnorm: c=%d groups=%d", c0 + c1, groups);
     if (n_img == 0 || hw == 0) return MVLDM_OK;   // empty: buffers may be null
     MVLDM_REQUIRE(x && y && gamma && beta && stats_ws, "groupnorm: null pointer");
@@ -330,7 +338,7 @@ int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, co
             const dim3 grid(n_img * (c / f_span)), block(f_nthr);
 #define MVLDM_GN_FUSED(KT_)                                                                                             \
     hipLaunchKernelGGL((gn_fused_kernel<T, KT_>), grid, block, 0, s, reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(x1), \
-                       c0, reinterpret_cast<T*>(y), gamma, beta, hw, c, groups, f_span, eps, silu)
+                       c0, reinterpret_cast<T*>(y), gamma, beta, hw, c, groups, f_span, eps, silu, stats_out)
             if (f_kt <= 2) MVLDM_GN_FUSED(2);
             else if (f_kt <= 4) MVLDM_GN_FUSED(4);
             else if (f_kt <= 8) MVLDM_GN_FUSED(8);
@@ -354,7 +362,7 @@ int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, co
         if (rc) return rc;
         hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(n_img * nchunk), dim3(256), smem, s, reinterpret_cast<const T*>(x),
                            reinterpret_cast<const T*>(x1), c0, reinterpret_cast<T*>(y), gamma, beta, reinterpret_cast<const double*>(stats_ws), hw, c, groups,
-                           rows_per_chunk, nchunk, eps, silu);
+                           rows_per_chunk, nchunk, eps, silu, stats_out);
         return check_launch();
     });
 }
@@ -386,8 +394,8 @@ int layernorm_run(const void* x, void* y, const float* gamma, const float* beta,
 
 extern "C" int mvldm_groupnorm_fwd(const void* x0, const void* x1, void* y, const float* gamma, const float* beta,
                                    int n_img, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
-                                   void* stats_ws, mvldm_stream_t stream) {
-    return mvldm::groupnorm_run(x0, x1, y, gamma, beta, n_img, hw, c0, c1, groups, eps, silu, dtype, stats_ws,
+                                   void* stats_ws, float* stats_out, mvldm_stream_t stream) {
+    return mvldm::groupnorm_run(x0, x1, y, gamma, beta, n_img, hw, c0, c1, groups, eps, silu, dtype, stats_ws, stats_out,
                                 (hipStream_t)stream);
 }
 

@@ -7,12 +7,12 @@
 namespace mvldm {
 int igemm_run(const mvldm_igemm_desc& d, hipStream_t s);
 int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, const float* beta, int n_img, int hw, int c0,
-                  int c1, int groups, float eps, int silu, int dtype, void* stats_ws, hipStream_t s);
+                  int c1, int groups, float eps, int silu, int dtype, void* stats_ws, float* stats_out, hipStream_t s);
 int layernorm_run(const void* x, void* y, const float* gamma, const float* beta, int rows, int c, float eps, int dtype,
                   hipStream_t s);
 int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,
                   int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len, float scale, int dtype,
-                  hipStream_t s);
+                  float* lse, int lse_ld, hipStream_t s);
 int temb_run(const int64_t* ts, const float* freqs, void* out, int n, int dim, int flip, int dst_dtype, hipStream_t s);
 int eltwise_run(const void* x, void* y, size_t n, int op, int src_dtype, int dst_dtype, hipStream_t s);
 int ddim_run(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img, const int32_t* uncond_img,
@@ -34,7 +34,7 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         case MVLDM_OP_GROUPNORM: {
             const auto& g = op.u.groupnorm;
             return groupnorm_run(g.x, g.x1, g.y, g.gamma, g.beta, g.n_img, g.hw, g.c0, g.c1, g.groups, g.eps, g.silu, g.dtype,
-                                 g.stats_ws, s);
+                                 g.stats_ws, g.stats_out, s);
         }
         case MVLDM_OP_LAYERNORM: {
             const auto& l = op.u.layernorm;
@@ -43,7 +43,7 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         case MVLDM_OP_ATTENTION: {
             const auto& a = op.u.attention;
             return attention_run(a.q, a.k, a.v, a.out, a.ld_q, a.ld_k, a.ld_v, a.ld_o, a.heads, a.head_dim, a.seg, a.n_seg,
-                                 a.max_q_len, a.scale, a.dtype, s);
+                                 a.max_q_len, a.scale, a.dtype, a.lse, a.lse_ld, s);
         }
         case MVLDM_OP_TIMESTEP_EMBED: {
             const auto& t = op.u.temb;

@@ -1,0 +1,413 @@
+// Training-step kernels that are neither GEMMs nor norms (include/mvldm.h, "Training"): column sums (bias /
+// time-embedding-row gradients), SiLU / GEGLU forward+backward, gradient accumulation, 2x2 sum pooling (backward of the
+// nearest-2x upsample), noise injection, the MSE loss and its gradient, global gradient norm + clip coefficient, fused AdamW.
+// All HBM-bound streaming kernels: 16-byte accesses, one pass over their operands.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mvldm {
+
+static inline int grid_for(size_t n, int per = 256) { return (int)std::min<size_t>((n + per - 1) / per, 8192); }
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x), Phi through the same A-S 7.1.26 erf as the forward (common.h)
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float phi = 0.5f * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+    return phi + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- column sums ------------------------------------------------------------------------------------
+// x [n_seg * rows_per_seg][ld] (activation dtype), columns [0, n): part[seg][chunk][n] = sum over the chunk's rows.
+// A thread owns one 16-byte chunk column; the block sweeps RB rows at a time; deterministic (fixed order, no atomics to HBM).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ part, int rows_per_seg,
+                                                             int n, int ld, int rows_per_chunk, int nchunk) {
+    constexpr int EPC = Elt<T>::EPC;
+    extern __shared__ float s_acc[];          // [RB][span*EPC]
+    const int seg = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const int ncc = n / EPC;
+    const int r0 = chunk * rows_per_chunk, r1 = min(rows_per_seg, r0 + rows_per_chunk);
+    const T* base = x + (size_t)seg * rows_per_seg * ld;
+    float* out = part + ((size_t)seg * nchunk + chunk) * n;
+    for (int cc0 = 0; cc0 < ncc; cc0 += 256) {
+        const int span = min(ncc - cc0, 256);
+        const int RB = max(1, 256 / span);
+        const int cc = cc0 + threadIdx.x % span, rl = threadIdx.x / span;
+        float a[EPC];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) a[i] = 0.f;
+        if (rl < RB) {
+            for (int r = r0 + rl; r < r1; r += RB) {
+                const Chunk<T> v = load_chunk<T>(base + (size_t)r * ld + cc * EPC);
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) a[i] += v.get(i);
+            }
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) s_acc[(rl * span + (cc - cc0)) * EPC + i] = a[i];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < span * EPC; e += 256) {
+            float t = 0.f;
+            for (int r = 0; r < RB; ++r) t += s_acc[r * span * EPC + e];
+            out[cc0 * EPC + e] = t;
+        }
+        __syncthreads();
+    }
+}
+// dst[seg][n] (ld_dst) = / += sum over chunks (per_seg), or dst[n] += sum over segments and chunks (!per_seg)
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ dst, int n_seg,
+                                                            int nchunk, int n, int ld_dst, int per_seg, int accumulate) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = per_seg ? n_seg * n : n;
+    if (idx >= total) return;
+    const int seg = per_seg ? idx / n : 0, col = per_seg ? idx - seg * n : idx;
+    float t = 0.f;
+    const int s0 = per_seg ? seg : 0, s1 = per_seg ? seg + 1 : n_seg;
+    for (int sg = s0; sg < s1; ++sg)
+        for (int k = 0; k < nchunk; ++k) t += part[((size_t)sg * nchunk + k) * n + col];
+    float* o = dst + (size_t)seg * ld_dst + col;
+    *o = accumulate ? *o + t : t;
+}
+
+// ---- elementwise forward/backward --------------------------------------------------------------------
+enum { TE_SILU_BWD = 0, TE_ADD = 1, TE_GEGLU_FWD = 2, TE_GEGLU_BWD = 3 };
+
+// dx = dy * silu'(x)
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const TX* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = to_f32<TX>(x[i]), s = sigmoid_f(v);
+        dx[i] = from_f32<T>(to_f32<T>(dy[i]) * s * (1.0f + v * (1.0f - s)));
+    }
+}
+// a += b   (gradient accumulation where two consumers feed one tensor)
+template <typename T> __global__ __launch_bounds__(256) void add_kernel(T* __restrict__ a, const T* __restrict__ b, size_t nchunks) {
+    constexpr int EPC = Elt<T>::EPC;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+        Chunk<T> u = load_chunk<T>(a + i * EPC);
+        const Chunk<T> v = load_chunk<T>(b + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) u.set(e, u.get(e) + v.get(e));
+        store_chunk<T>(a + i * EPC, u);
+    }
+}
+// GEGLU (diffusers GEGLU / mvdream attention.py:60-73): ag [rows][2D] = [value | gate];  h = value * gelu(gate)
+template <typename T> __global__ __launch_bounds__(256) void geglu_fwd_kernel(const T* __restrict__ ag, T* __restrict__ h, size_t rows, int D) {
+    constexpr int EPC = Elt<T>::EPC;
+    const int dc = D / EPC;
+    const size_t total = rows * dc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / dc;
+        const int c = (int)(i - r * dc) * EPC;
+        const Chunk<T> a = load_chunk<T>(ag + r * 2 * D + c), g = load_chunk<T>(ag + r * 2 * D + D + c);
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, a.get(e) * gelu_erf_f(g.get(e)));
+        store_chunk<T>(h + r * D + c, o);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ ag, const T* __restrict__ dh, T* __restrict__ dag, size_t rows, int D) {
+    constexpr int EPC = Elt<T>::EPC;
+    const int dc = D / EPC;
+    const size_t total = rows * dc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / dc;
+        const int c = (int)(i - r * dc) * EPC;
+        const Chunk<T> a = load_chunk<T>(ag + r * 2 * D + c), g = load_chunk<T>(ag + r * 2 * D + D + c), d = load_chunk<T>(dh + r * D + c);
+        Chunk<T> da, dg;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            da.set(e, d.get(e) * gelu_erf_f(g.get(e)));
+            dg.set(e, d.get(e) * a.get(e) * gelu_grad_f(g.get(e)));
+        }
+        store_chunk<T>(dag + r * 2 * D + c, da);
+        store_chunk<T>(dag + r * 2 * D + D + c, dg);
+    }
+}
+// backward of nearest-2x upsampling: dx[n][i][j][c] = sum of the 2x2 block of du[n][2i..][2j..][c]
+template <typename T> __global__ __launch_bounds__(256) void pool2x2_kernel(const T* __restrict__ du, T* __restrict__ dx, int n_img, int h, int w, int c) {
+    constexpr int EPC = Elt<T>::EPC;
+    const int cc = c / EPC;
+    const size_t total = (size_t)n_img * h * w * cc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ch = (int)(i % cc) * EPC;
+        const size_t p = i / cc;
+        const int x = (int)(p % w), y = (int)((p / w) % h), img = (int)(p / ((size_t)w * h));
+        const T* s = du + (((size_t)img * 2 * h + 2 * y) * (2 * w) + 2 * x) * c + ch;
+        const Chunk<T> a = load_chunk<T>(s), b = load_chunk<T>(s + c), d = load_chunk<T>(s + (size_t)2 * w * c), e = load_chunk<T>(s + (size_t)2 * w * c + c);
+        Chunk<T> o;
+#pragma unroll
+        for (int k = 0; k < EPC; ++k) o.set(k, (a.get(k) + b.get(k)) + (d.get(k) + e.get(k)));
+        store_chunk<T>(dx + p * c + ch, o);
+    }
+}
+
+// ---- noise injection, loss ---------------------------------------------------------------------------------
+// DDIMScheduler.add_noise (diffusion_wrapper.py:370): noisy = sqrt(a_t) * x0 + sqrt(1 - a_t) * noise, per image coefficients
+// coef [n][2]; x0 / noise fp32 NCHW [n][c][hw]; written into channels [c_off, c_off + c) of NHWC image img_map[i]
+// (separately rounded fp32 mul/mul/add like the torch expression)
+template <typename T>
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ coef,
+                                                        T* __restrict__ dst, int n, int c, int hw, int dst_c, int dst_c_off, const int32_t* __restrict__ img_map) {
+    const size_t total = (size_t)n * hw * c;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int ch = (int)(idx % c);
+        const size_t pi = idx / c;
+        const int pix = (int)(pi % hw), img = (int)(pi / hw);
+        const size_t s = ((size_t)img * c + ch) * hw + pix;
+        const float v = __fadd_rn(__fmul_rn(coef[2 * img], x0[s]), __fmul_rn(coef[2 * img + 1], noise[s]));
+        const int dimg = img_map ? img_map[img] : img;
+        dst[((size_t)dimg * hw + pix) * dst_c + dst_c_off + ch] = from_f32<T>(v);
+    }
+}
+
+// F.mse_loss(pred[:, v_c:], noise, reduction="mean") and its gradient (diffusion_wrapper.py:405-411):
+// pred fp32 NHWC [n_img][hw][c]; target t: image tgt_img[t] of pred, noise fp32 NCHW [n_tgt][c][hw].
+// partial[block] = sum (pred - noise)^2;  dpred [n_img][hw][dc] (activation dtype, zero-filled by the caller for the
+// non-target images and the padding channels) = grad_scale * 2 (pred - noise) / N
+template <typename T>
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ noise, const int32_t* __restrict__ tgt_img,
+                                                  int n_tgt, int hw, int c, double* __restrict__ partial, T* __restrict__ dpred, int dc, float gscale) {
+    __shared__ double s_red[256];
+    const size_t per = (size_t)hw * c, total = (size_t)n_tgt * per;
+    double acc = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int t = (int)(idx / per);
+        const size_t rem = idx - (size_t)t * per;
+        const int pix = (int)(rem / c), ch = (int)(rem - (size_t)pix * c);
+        const int img = tgt_img[t];
+        const float d = pred[((size_t)img * hw + pix) * c + ch] - noise[((size_t)t * c + ch) * hw + pix];
+        acc += (double)d * (double)d;
+        if (dpred) dpred[((size_t)img * hw + pix) * dc + ch] = from_f32<T>(gscale * d);
+    }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+// out[0] (+)= scale * sum(partial[0..n))
+__global__ __launch_bounds__(256) void sum_finish_kernel(const double* __restrict__ partial, int n, double scale, float* __restrict__ out, int accumulate) {
+    __shared__ double s_red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)(scale * s_red[0]);
+}
+
+// ---- optimizer ----------------------------------------------------------------------------------------------
+// sum of squares of a flat fp32 buffer -> partial[block] (fp64)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* __restrict__ partial) {
+    __shared__ double s_red[256];
+    double acc = 0.0;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+        acc += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) { const float v = g[n4 * 4 + threadIdx.x]; acc += (double)v * v; }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+// torch.nn.utils.clip_grad_norm_: total = sqrt(extra_sumsq + sum partial) [extra: other ranks' shards, already all-reduced];
+// norm_out[0] = total, norm_out[1] = clip coefficient min(1, max_norm / (total + 1e-6))  (max_norm <= 0: no clipping)
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ partial, int n, const float* __restrict__ sumsq_in, float max_norm,
+                                                        float* __restrict__ norm_out) {
+    __shared__ double s_red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double tot2 = sumsq_in ? (double)sumsq_in[0] : s_red[0];
+        const float total = (float)sqrt(tot2);
+        norm_out[0] = total;
+        norm_out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (total + 1e-6f)) : 1.0f;
+        norm_out[2] = (float)s_red[0];      // this buffer's own sum of squares (what a sharded optimizer all-reduces)
+    }
+}
+// torch.optim.AdamW (decoupled weight decay, no amsgrad), one launch over the flat fp32 master parameters:
+//   g *= gscale * clip;  p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)          (bc = 1 - beta^step, computed on the host in fp64)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    size_t n, float lr, float b1, float b2, float eps, float wd, float step_size, float inv_sqrt_bc2,
+                                                    float gscale, const float* __restrict__ clip) {
+    const float gs = gscale * (clip ? clip[1] : 1.0f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+        p[i] = pi;
+    }
+}
+
+// ---- host entry points ---------------------------------------------------------------------------------------
+int colsum_run(const void* x, float* dst, float* ws, size_t ws_bytes, int n_seg, int rows_per_seg, int n, int ld, int ld_dst, int per_seg,
+               int accumulate, int dtype, hipStream_t s) {
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    if (n_seg == 0 || rows_per_seg == 0 || n == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(x && dst && ws, "colsum: null pointer");
+    MVLDM_REQUIRE(n % epc == 0 && ld % epc == 0 && ld >= n, "colsum: n=%d ld=%d must be multiples of %d", n, ld, epc);
+    int nchunk = std::max(1, std::min(std::min(rows_per_seg / 16, 64), (2048 + n_seg - 1) / n_seg));
+    const int rpc = (rows_per_seg + nchunk - 1) / nchunk;
+    nchunk = (rows_per_seg + rpc - 1) / rpc;
+    MVLDM_REQUIRE((size_t)n_seg * nchunk * n * sizeof(float) <= ws_bytes, "colsum: workspace of %zu bytes too small (need %zu)", ws_bytes,
+                  (size_t)n_seg * nchunk * n * sizeof(float));
+    const int span = std::min(n / epc, 256), rb = std::max(1, 256 / span);
+    const size_t smem = (size_t)rb * span * epc * sizeof(float);
+    int rc = dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3(n_seg * nchunk), dim3(256), smem, s, reinterpret_cast<const T*>(x), ws, rows_per_seg, n, ld, rpc, nchunk);
+        return check_launch();
+    });
+    if (rc) return rc;
+    const int total = per_seg ? n_seg * n : n;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, dst, n_seg, nchunk, n, ld_dst, per_seg, accumulate);
+    return check_launch();
+}
+
+int train_eltwise_run(int op, const void* a, const void* b, void* out, size_t rows, int d, int a_dtype, int dtype, hipStream_t s) {
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    if (rows == 0 || d == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(a && out, "train_eltwise: null pointer");
+    return dispatch_dtype(dtype, [&](auto t) -> int {
+        using T = decltype(t);
+        const size_t n = rows * (size_t)d;
+        switch (op) {
+            case TE_SILU_BWD:
+                MVLDM_REQUIRE(b, "silu_bwd: null dy");
+                return dispatch_dtype(a_dtype, [&](auto tx) {
+                    using TX = decltype(tx);
+                    hipLaunchKernelGGL((silu_bwd_kernel<TX, T>), dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const TX*>(a),
+                                       reinterpret_cast<const T*>(b), reinterpret_cast<T*>(out), n);
+                    return check_launch();
+                });
+            case TE_ADD:
+                MVLDM_REQUIRE(n % epc == 0, "add: element count must be a multiple of %d", epc);
+                hipLaunchKernelGGL(add_kernel<T>, dim3(grid_for(n / epc)), dim3(256), 0, s, reinterpret_cast<T*>(out), reinterpret_cast<const T*>(a), n / epc);
+                return check_launch();
+            case TE_GEGLU_FWD:
+                MVLDM_REQUIRE(d % epc == 0, "geglu: D=%d", d);
+                hipLaunchKernelGGL(geglu_fwd_kernel<T>, dim3(grid_for(n / epc)), dim3(256), 0, s, reinterpret_cast<const T*>(a), reinterpret_cast<T*>(out), rows, d);
+                return check_launch();
+            case TE_GEGLU_BWD:
+                MVLDM_REQUIRE(d % epc == 0 && b, "geglu_bwd: D=%d", d);
+                hipLaunchKernelGGL(geglu_bwd_kernel<T>, dim3(grid_for(n / epc)), dim3(256), 0, s, reinterpret_cast<const T*>(a), reinterpret_cast<const T*>(b),
+                                   reinterpret_cast<T*>(out), rows, d);
+                return check_launch();
+            default: return set_error(MVLDM_ERR_ARG, "train_eltwise: op %d", op);
+        }
+    });
+}
+
+int pool2x2_run(const void* du, void* dx, int n_img, int h, int w, int c, int dtype, hipStream_t s) {
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    if (n_img == 0 || h == 0 || w == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(du && dx && c % epc == 0, "pool2x2: bad arguments");
+    return dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(pool2x2_kernel<T>, dim3(grid_for((size_t)n_img * h * w * (c / epc))), dim3(256), 0, s, reinterpret_cast<const T*>(du),
+                           reinterpret_cast<T*>(dx), n_img, h, w, c);
+        return check_launch();
+    });
+}
+
+int add_noise_run(const float* x0, const float* noise, const float* coef, void* dst, int n, int c, int hw, int dst_c, int dst_c_off, int dst_dtype,
+                  const int32_t* img_map, hipStream_t s) {
+    if (n == 0 || hw == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(x0 && noise && coef && dst && dst_c_off + c <= dst_c, "add_noise: bad arguments");
+    return dispatch_dtype(dst_dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(add_noise_kernel<T>, dim3(grid_for((size_t)n * c * hw)), dim3(256), 0, s, x0, noise, coef, reinterpret_cast<T*>(dst), n, c, hw,
+                           dst_c, dst_c_off, img_map);
+        return check_launch();
+    });
+}
+
+constexpr int kLossBlocks = 256;
+int mse_run(const float* pred, const float* noise, const int32_t* tgt_img, int n_tgt, int hw, int c, float* loss, int accumulate, float loss_scale,
+            void* dpred, int dc, int dtype, float grad_scale, double* ws, hipStream_t s) {
+    MVLDM_REQUIRE(pred && noise && tgt_img && loss && ws && n_tgt > 0 && hw > 0, "mse_loss: bad arguments");
+    MVLDM_REQUIRE(!dpred || dc >= c, "mse_loss: dpred has %d channels, need %d", dc, c);
+    const double N = (double)n_tgt * hw * c;
+    int rc = dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(mse_kernel<T>, dim3(kLossBlocks), dim3(256), 0, s, pred, noise, tgt_img, n_tgt, hw, c, ws, reinterpret_cast<T*>(dpred), dc,
+                           (float)(2.0 * grad_scale / N));
+        return check_launch();
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, ws, kLossBlocks, (double)loss_scale / N, loss, accumulate);
+    return check_launch();
+}
+
+constexpr int kNormBlocks = 1024;
+int grad_norm_run(const float* g, size_t n, const float* sumsq_in, float max_norm, float* norm_out, double* ws, hipStream_t s) {
+    MVLDM_REQUIRE(g && norm_out && ws, "grad_norm: null pointer");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(kNormBlocks), dim3(256), 0, s, g, n, ws);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, ws, kNormBlocks, sumsq_in, max_norm, norm_out);
+    return check_launch();
+}
+
+int adamw_run(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+              float grad_scale, const float* clip, hipStream_t s) {
+    if (n == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(p && g && m && v && step >= 1, "adamw: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), grad_scale, clip);
+    return check_launch();
+}
+
+}  // namespace mvldm
+
+using namespace mvldm;
+extern "C" int mvldm_colsum(const void* x, float* dst, float* workspace, size_t workspace_bytes, int n_seg, int rows_per_seg, int n, int ld, int ld_dst,
+                            int per_seg, int accumulate, int dtype, mvldm_stream_t stream) {
+    return colsum_run(x, dst, workspace, workspace_bytes, n_seg, rows_per_seg, n, ld, ld_dst, per_seg, accumulate, dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_train_eltwise(int op, const void* a, const void* b, void* out, size_t rows, int d, int a_dtype, int dtype, mvldm_stream_t stream) {
+    return train_eltwise_run(op, a, b, out, rows, d, a_dtype, dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_pool2x2_sum(const void* du, void* dx, int n_img, int h, int w, int c, int dtype, mvldm_stream_t stream) {
+    return pool2x2_run(du, dx, n_img, h, w, c, dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_add_noise(const float* x0, const float* noise, const float* coef, void* dst, int n, int c, int hw, int dst_c, int dst_c_off,
+                               int dst_dtype, const int32_t* img_map, mvldm_stream_t stream) {
+    return add_noise_run(x0, noise, coef, dst, n, c, hw, dst_c, dst_c_off, dst_dtype, img_map, (hipStream_t)stream);
+}
+extern "C" int mvldm_mse_loss(const float* pred, const float* noise, const int32_t* tgt_img, int n_tgt, int hw, int c, float* loss, int accumulate,
+                              float loss_scale, void* dpred, int dpred_c, int dpred_dtype, float grad_scale, double* workspace, mvldm_stream_t stream) {
+    return mse_run(pred, noise, tgt_img, n_tgt, hw, c, loss, accumulate, loss_scale, dpred, dpred_c, dpred_dtype, grad_scale, workspace, (hipStream_t)stream);
+}
+extern "C" int mvldm_grad_norm(const float* g, size_t n, const float* sumsq_in, float max_norm, float* norm_out, double* workspace, mvldm_stream_t stream) {
+    return grad_norm_run(g, n, sumsq_in, max_norm, norm_out, workspace, (hipStream_t)stream);
+}
+extern "C" int mvldm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int step, float grad_scale, const float* clip, mvldm_stream_t stream) {
+    return adamw_run(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, clip, (hipStream_t)stream);
+}

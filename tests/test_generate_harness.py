@@ -116,4 +116,4 @@ def test_cli_runs_the_released_topology(capsys):
     assert rc == 0
     line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["mode"] == "anchored" and out["ddim_steps"] == 2 and out["n_gpus"] == 1 and out["views"] == 2 * 12 and out["views_per_s"] > 0
+    assert out["mode"] == "anchored" and out["ddim_steps"] == 2 and out["n_gpus"] == 1 and out["views"] == 2 * 13 and out["views_per_s"] > 0
