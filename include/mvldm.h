@@ -91,9 +91,14 @@ size_t mvldm_igemm_workspace_bytes(const mvldm_igemm_desc* d);
  * interleaves rows n and n + n_out/2 in blocks of 32; `k_order` 1 stores k as (channel block of 64 [32 for
  * f32], tap, channel in block) so that the 9 taps of one channel block are consecutive K-tiles (their
  * activation reads hit L2 instead of crossing the fabric 9 times); needs c_pad % 64 == 0.  replaces: nothing in the reference (weights
- * there stay in torch layout); this is the one-time load-time transform. */
+ * there stay in torch layout); this is the one-time load-time transform.
+ * `transpose` != 0 packs the weight of the DATA-GRADIENT convolution instead (backward of Conv2d / Linear w.r.t. its input):
+ * rows are `n_rows` INPUT channels starting at `c_off` (a skip-concat conv yields two gradients: two packs), K runs over
+ * (tap, output channel) with the taps flipped: dst[r][(tap', n)] = src[n][c_off + r][taps-1-tap']; c_pad then pads n_out,
+ * n_pad pads n_rows. */
 int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksize, int c_pad, int n_pad,
-                      int k_pad, int geglu, int k_order, int dst_dtype, mvldm_stream_t stream);
+                      int k_pad, int geglu, int k_order, int dst_dtype, int transpose, int c_off, int n_rows,
+                      mvldm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.   replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D
@@ -103,11 +108,12 @@ int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksiz
  * otherwise): the up-path skip concat (mvunet.py:176) feeds norm1 directly and is never materialised;
  * groups are taken over the concatenated c0+c1 channels and y is [n_img][hw][c0+c1].
  * stats_ws: >= n_img * MVLDM_GN_MAX_CHUNKS * groups * 2 doubles.
+ * stats_out (optional): fp32 [n_img][groups][2] = (mean, rstd), saved for mvldm_groupnorm_bwd.
  */
 #define MVLDM_GN_MAX_CHUNKS 32
 int mvldm_groupnorm_fwd(const void* x0, const void* x1, void* y, const float* gamma, const float* beta, int n_img,
                         int hw, int c0, int c1, int groups, float eps, int silu, int dtype, void* stats_ws,
-                        mvldm_stream_t stream);
+                        float* stats_out, mvldm_stream_t stream);
 
 /* LayerNorm over the last dim of [rows][c].  replaces torch.nn.LayerNorm in BasicTransformerBlock
  * (diffusers) and BasicTransformerBlock3D norm1-3 (mvdream/attention.py:286-288,363-367). */
@@ -123,10 +129,12 @@ int mvldm_layernorm_fwd(const void* x, void* y, const float* gamma, const float*
  * q/k/v/out are row-major token matrices; head h occupies columns [h*head_dim, (h+1)*head_dim);
  * ld_* are row strides in elements, so q/k/v may alias one fused [tokens][3C] projection.
  * seg: device int32 [n_seg][4] = {q_row0, q_len, kv_row0, kv_len}.
+ * lse (optional): fp32 [heads][lse_ld], entry [h][q row] = log2-domain log-sum-exp of the scaled scores of query row
+ * `q row` (P = exp2(s * scale * log2(e) - lse)): saved for mvldm_attention_bwd.
  */
 int mvldm_attention_fwd(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v,
                         int ld_o, int heads, int head_dim, const int32_t* seg, int n_seg, int max_q_len,
-                        float scale, int dtype, mvldm_stream_t stream);
+                        float scale, int dtype, float* lse, int lse_ld, mvldm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sinusoidal timestep projection.   replaces diffusers Timesteps(320, flip_sin_to_cos=True, shift 0)
@@ -202,6 +210,104 @@ int mvldm_ray_encode(const float* extrinsics, const float* intrinsics, int n_cam
 int mvldm_posterior_sample(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale,
                            mvldm_stream_t stream);
 
+/* ================================================================================================
+ * Training: the backward kernels of the same path.   replaces torch.autograd through
+ * MultiViewUNet.forward inside DiffusionWrapper.training_step (src/model/diffusion_wrapper.py:324-411:
+ * add_noise :370, denoiser.forward :401, F.mse_loss :405-411) and the optimizer step Lightning drives for it
+ * (configure_optimizers :1111-1122: AdamW lr 2e-5 + LinearLR warm-up, config/experiment/baseline.yaml:62-73;
+ * Trainer(gradient_clip_val=0.1, accumulate_grad_batches=2), src/main.py:119-136, config/main.yaml:82-84).
+ * Data gradients of convolutions / Linears are mvldm_igemm_fwd on weights packed with `transpose` (above).
+ * ================================================================================================ */
+
+/* Weight gradient of a convolution / Linear: grad[n][c][ky][kx] (PyTorch fp32 layout; [n][c] for a Linear)
+ *   = / += sum over output pixels m of dy[m][n] * A[m][(tap, c)], A = the forward pass's on-the-fly gather
+ * (two sources concatenated along C, stride, zero padding, nearest-2x upsampling: same fields as mvldm_igemm_desc).
+ * dy: [m][dy_ld] activation dtype, columns [0, n_out) used -- a column slice of a wider matrix (fused QKV / all
+ * time_emb_proj at once) is addressed by offsetting the pointer.  c_in <= c0 + c1: padding channels of the gather
+ * (conv_in: 11 -> 16) are dropped from grad.  workspace: fp32 split-K slabs, >= n_out * ksize^2 * (c0+c1) * 4 bytes
+ * (more lets small layers split the pixel range over more workgroups); reduced in a fixed order: deterministic. */
+typedef struct mvldm_wgrad_desc {
+    const void* src0; const void* src1; const void* dy;
+    float* grad;
+    float* workspace; size_t workspace_bytes;
+    int32_t c0, c1, c_in;
+    int32_t n_img, h_in, w_in, h_out, w_out;
+    int32_t ksize, stride, pad, upsample;      /* upsample: 0 | 1 (nearest-2x gather in front of a 3x3 conv) */
+    int32_t n_out, dy_ld;
+    int32_t act_dtype;
+    int32_t accumulate;                        /* 0: grad = ...; 1: grad += ... (gradient accumulation over micro-batches) */
+} mvldm_wgrad_desc;
+int mvldm_igemm_wgrad(const mvldm_wgrad_desc* d, mvldm_stream_t stream);
+
+/* Column sums of a [n_seg * rows_per_seg][ld] activation matrix, columns [0, n): bias gradients (per_seg = 0:
+ * dst[n] (+)= sum over all rows) and the gradient of the per-image time-embedding row added by ResnetBlock2D
+ * (per_seg = 1: dst[seg][n] (ld_dst) (+)= sum over the rows of image seg).  workspace: fp32, >= n_seg * 64 * n floats. */
+int mvldm_colsum(const void* x, float* dst, float* workspace, size_t workspace_bytes, int n_seg, int rows_per_seg, int n,
+                 int ld, int ld_dst, int per_seg, int accumulate, int dtype, mvldm_stream_t stream);
+
+/* GroupNorm(+SiLU) backward (NHWC, optional two-source concat input as in the forward): dx0 / dx1 written,
+ * dgamma / dbeta ACCUMULATED (+=).  stats: the forward's stats_out.  workspace: fp32,
+ * >= n_img * MVLDM_GN_MAX_CHUNKS * (c0+c1) * 2 floats. */
+int mvldm_groupnorm_bwd(const void* x0, const void* x1, const void* dy, void* dx0, void* dx1, const float* gamma,
+                        const float* beta, const float* stats, float* dgamma, float* dbeta, int n_img, int hw, int c0,
+                        int c1, int groups, int silu, int dtype, float* workspace, size_t workspace_bytes,
+                        mvldm_stream_t stream);
+/* LayerNorm backward over [rows][c]: dx written, dgamma / dbeta accumulated.  workspace: fp32, >= 512 * c * 2 floats. */
+int mvldm_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma, float* dbeta,
+                        int rows, int c, float eps, int dtype, float* workspace, size_t workspace_bytes,
+                        mvldm_stream_t stream);
+
+/* Flash-attention backward (probabilities recomputed from `lse`; see mvldm_attention_fwd for the layout conventions).
+ * dq/dk/dv may be column slices of one [tokens][3C] gradient of a fused QKV projection.  delta: fp32 scratch
+ * [heads][stat_ld] (written here: sum_d dout * out per query row); lse: [heads][stat_ld] from the forward.
+ * total_q_rows: number of query rows covered by the segments (rows 0 .. total_q_rows-1 of q/out/dout). */
+typedef struct mvldm_attn_bwd_desc {
+    const void* q; const void* k; const void* v; const void* out; const void* dout;
+    void* dq; void* dk; void* dv;
+    const float* lse; float* delta;
+    const int32_t* seg;
+    int32_t ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
+    int32_t heads, head_dim, n_seg, max_q_len, max_kv_len, total_q_rows, stat_ld, dtype;
+    float scale;
+} mvldm_attn_bwd_desc;
+int mvldm_attention_bwd(const mvldm_attn_bwd_desc* d, mvldm_stream_t stream);
+
+/* Elementwise training ops on [rows][d] activation matrices:
+ *   MVLDM_TE_SILU_BWD   out = b * silu'(a)                      (a: pre-activation, dtype a_dtype; b: upstream gradient)
+ *   MVLDM_TE_ADD        out += a                                 (gradient accumulation; b unused)
+ *   MVLDM_TE_GEGLU_FWD  out[rows][d] = a[:, :d] * gelu(a[:, d:])            (a: [rows][2d]; diffusers GEGLU / mvdream attention.py:60-73)
+ *   MVLDM_TE_GEGLU_BWD  out[rows][2d] = d/da of the above times b[rows][d] */
+enum { MVLDM_TE_SILU_BWD = 0, MVLDM_TE_ADD = 1, MVLDM_TE_GEGLU_FWD = 2, MVLDM_TE_GEGLU_BWD = 3 };
+int mvldm_train_eltwise(int op, const void* a, const void* b, void* out, size_t rows, int d, int a_dtype, int dtype,
+                        mvldm_stream_t stream);
+/* backward of nearest-2x upsampling: dx[n][i][j][c] = sum of the 2x2 block of du [n][2h][2w][c] */
+int mvldm_pool2x2_sum(const void* du, void* dx, int n_img, int h, int w, int c, int dtype, mvldm_stream_t stream);
+/* backward of a stride-2 subsampling: out [n][2h][2w][c] = x [n][h][w][c] at the even positions, zero elsewhere */
+int mvldm_zero_insert2x(const void* x, void* out, int n_img, int h, int w, int c, int dtype, mvldm_stream_t stream);
+
+/* DDIMScheduler.add_noise (diffusion_wrapper.py:370) fused with the UNet-input assembly: channels [dst_c_off, +c) of NHWC
+ * image img_map[i] = sqrt(a_t) * x0[i] + sqrt(1 - a_t) * noise[i]; x0 / noise fp32 NCHW [n][c][hw], coef fp32 [n][2]. */
+int mvldm_add_noise(const float* x0, const float* noise, const float* coef, void* dst, int n, int c, int hw, int dst_c,
+                    int dst_c_off, int dst_dtype, const int32_t* img_map, mvldm_stream_t stream);
+/* F.mse_loss(pred[:, v_c:], noise, reduction="mean") (diffusion_wrapper.py:405-411) and its gradient: pred fp32 NHWC
+ * [n_img][hw][c]; target t is image tgt_img[t]; noise fp32 NCHW [n_tgt][c][hw].  loss[0] (+)= loss_scale * mean;
+ * dpred (optional, [n_img][hw][dpred_c], zero-filled by the caller) = grad_scale * 2 (pred - noise) / N at the target
+ * images.  workspace: 256 doubles. */
+int mvldm_mse_loss(const float* pred, const float* noise, const int32_t* tgt_img, int n_tgt, int hw, int c, float* loss,
+                   int accumulate, float loss_scale, void* dpred, int dpred_c, int dpred_dtype, float grad_scale,
+                   double* workspace, mvldm_stream_t stream);
+
+/* torch.nn.utils.clip_grad_norm_ over a flat fp32 gradient buffer (Lightning gradient_clip_val, src/main.py:131):
+ * norm_out[0] = total norm, norm_out[1] = min(1, max_norm / (total + 1e-6)) (max_norm <= 0: 1), norm_out[2] = this
+ * buffer's sum of squares.  sumsq_in (optional, device): use this total sum of squares instead (a sharded optimizer
+ * all-reduces the per-rank norm_out[2] first).  workspace: 1024 doubles. */
+int mvldm_grad_norm(const float* g, size_t n, const float* sumsq_in, float max_norm, float* norm_out, double* workspace,
+                    mvldm_stream_t stream);
+/* torch.optim.AdamW step (decoupled weight decay, no amsgrad) on flat fp32 master parameters:
+ * g' = g * grad_scale * clip[1] (clip optional: norm_out of mvldm_grad_norm); step >= 1 is the 1-based step count. */
+int mvldm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float grad_scale, const float* clip, mvldm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Plans: a whole forward (UNet walk, VAE decoder, DDIM step) as a flat list of the ops above with
  * all pointers resolved -- built once by the host (mv_ldm_amd/plan.py), executed here without
@@ -211,7 +317,9 @@ int mvldm_posterior_sample(const float* moments, const float* noise, float* out,
 enum {
     MVLDM_OP_IGEMM = 1, MVLDM_OP_GROUPNORM, MVLDM_OP_LAYERNORM, MVLDM_OP_ATTENTION, MVLDM_OP_TIMESTEP_EMBED,
     MVLDM_OP_ELTWISE, MVLDM_OP_DDIM_STEP, MVLDM_OP_DDIM_ADVANCE, MVLDM_OP_NCHW_TO_NHWC, MVLDM_OP_NHWC_TO_NCHW,
-    MVLDM_OP_MEMCPY, MVLDM_OP_RAY_ENCODE, MVLDM_OP_POSTERIOR_SAMPLE
+    MVLDM_OP_MEMCPY, MVLDM_OP_RAY_ENCODE, MVLDM_OP_POSTERIOR_SAMPLE,
+    MVLDM_OP_WGRAD, MVLDM_OP_ATTENTION_BWD, MVLDM_OP_GROUPNORM_BWD, MVLDM_OP_LAYERNORM_BWD, MVLDM_OP_COLSUM,
+    MVLDM_OP_TRAIN_ELTWISE, MVLDM_OP_POOL2X2, MVLDM_OP_ZERO_INSERT, MVLDM_OP_ADD_NOISE, MVLDM_OP_MSE_LOSS, MVLDM_OP_FILL_ZERO
 };
 
 typedef struct mvldm_op {
@@ -220,11 +328,12 @@ typedef struct mvldm_op {
     union {
         mvldm_igemm_desc igemm;
         struct { const void* x; const void* x1; void* y; const float* gamma; const float* beta; void* stats_ws;
-                 int32_t n_img, hw, c0, c1, groups, silu, dtype; float eps; } groupnorm;
+                 int32_t n_img, hw, c0, c1, groups, silu, dtype; float eps; float* stats_out; } groupnorm;
         struct { const void* x; void* y; const float* gamma; const float* beta;
                  int32_t rows, c, dtype; float eps; } layernorm;
         struct { const void* q; const void* k; const void* v; void* out; const int32_t* seg;
-                 int32_t ld_q, ld_k, ld_v, ld_o, heads, head_dim, n_seg, max_q_len, dtype; float scale; } attention;
+                 int32_t ld_q, ld_k, ld_v, ld_o, heads, head_dim, n_seg, max_q_len, dtype; float scale;
+                 float* lse; int32_t lse_ld; } attention;
         struct { const int64_t* timesteps; const float* freqs; void* out;
                  int32_t n, dim, flip, dst_dtype; } temb;
         struct { const void* x; void* y; size_t n; int32_t op, src_dtype, dst_dtype; } eltwise;
@@ -238,6 +347,22 @@ typedef struct mvldm_op {
         struct { const float* extrinsics; const float* intrinsics; float* out_nchw; void* out_nhwc; const int32_t* img_map;
                  int32_t n_cam, h, w, nhwc_c, nhwc_c_off, nhwc_dtype; } rays;
         struct { const float* moments; const float* noise; float* out; int32_t n, c, hw; float scale; } posterior;
+        mvldm_wgrad_desc wgrad;
+        mvldm_attn_bwd_desc attention_bwd;
+        struct { const void* x0; const void* x1; const void* dy; void* dx0; void* dx1; const float* gamma; const float* beta;
+                 const float* stats; float* dgamma; float* dbeta; float* workspace; size_t workspace_bytes;
+                 int32_t n_img, hw, c0, c1, groups, silu, dtype; } groupnorm_bwd;
+        struct { const void* x; const void* dy; void* dx; const float* gamma; float* dgamma; float* dbeta; float* workspace;
+                 size_t workspace_bytes; int32_t rows, c, dtype; float eps; } layernorm_bwd;
+        struct { const void* x; float* dst; float* workspace; size_t workspace_bytes;
+                 int32_t n_seg, rows_per_seg, n, ld, ld_dst, per_seg, accumulate, dtype; } colsum;
+        struct { const void* a; const void* b; void* out; size_t rows; int32_t op, d, a_dtype, dtype; } train_eltwise;
+        struct { const void* src; void* dst; int32_t n_img, h, w, c, dtype; } resample;      /* pool2x2 / zero_insert2x */
+        struct { const float* x0; const float* noise; const float* coef; void* dst; const int32_t* img_map;
+                 int32_t n, c, hw, dst_c, dst_c_off, dst_dtype; } add_noise;
+        struct { const float* pred; const float* noise; const int32_t* tgt_img; float* loss; void* dpred; double* workspace;
+                 int32_t n_tgt, hw, c, accumulate, dpred_c, dpred_dtype; float loss_scale, grad_scale; } mse;
+        struct { void* dst; size_t bytes; } fill;
         struct { const void* src; void* dst; size_t bytes; } memcpy_;
     } u;
 } mvldm_op;

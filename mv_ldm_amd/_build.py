@@ -9,7 +9,8 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libmvldm_hip.so"
-SOURCES = ["api.cpp", "plan.cpp", "igemm.hip", "attention.hip", "norm.hip", "misc.hip"]
+SOURCES = ["api.cpp", "plan.cpp", "igemm.hip", "attention.hip", "norm.hip", "misc.hip",
+           "wgrad.hip", "attention_bwd.hip", "norm_bwd.hip", "train_misc.hip"]
 HEADERS = [CSRC / "common.h", CSRC.parent.parent / "include" / "mvldm.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
@@ -48,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode:
                 raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]

@@ -18,7 +18,10 @@ ELT_COPY, ELT_SILU = 0, 1
 GN_MAX_CHUNKS = 32
 
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_TIMESTEP_EMBED, OP_ELTWISE, OP_DDIM_STEP, OP_DDIM_ADVANCE,
- OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY, OP_RAY_ENCODE, OP_POSTERIOR_SAMPLE) = range(1, 14)
+ OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY, OP_RAY_ENCODE, OP_POSTERIOR_SAMPLE,
+ OP_WGRAD, OP_ATTENTION_BWD, OP_GROUPNORM_BWD, OP_LAYERNORM_BWD, OP_COLSUM, OP_TRAIN_ELTWISE, OP_POOL2X2, OP_ZERO_INSERT,
+ OP_ADD_NOISE, OP_MSE_LOSS, OP_FILL_ZERO) = range(1, 25)
+TE_SILU_BWD, TE_ADD, TE_GEGLU_FWD, TE_GEGLU_BWD = 0, 1, 2, 3
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 
@@ -37,7 +40,7 @@ class IgemmDesc(C.Structure):
 class _GroupNorm(C.Structure):
     _fields_ = [("x", vp), ("x1", vp), ("y", vp), ("gamma", vp), ("beta", vp), ("stats_ws", vp),
                 ("n_img", i32), ("hw", i32), ("c0", i32), ("c1", i32), ("groups", i32), ("silu", i32), ("dtype", i32),
-                ("eps", f32)]
+                ("eps", f32), ("stats_out", vp)]
 
 
 class _LayerNorm(C.Structure):
@@ -47,7 +50,7 @@ class _LayerNorm(C.Structure):
 class _Attention(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp), ("seg", vp),
                 ("ld_q", i32), ("ld_k", i32), ("ld_v", i32), ("ld_o", i32), ("heads", i32), ("head_dim", i32),
-                ("n_seg", i32), ("max_q_len", i32), ("dtype", i32), ("scale", f32)]
+                ("n_seg", i32), ("max_q_len", i32), ("dtype", i32), ("scale", f32), ("lse", vp), ("lse_ld", i32)]
 
 
 class _Temb(C.Structure):
@@ -87,10 +90,69 @@ class _Memcpy(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("bytes", sz)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("src0", vp), ("src1", vp), ("dy", vp), ("grad", vp), ("workspace", vp), ("workspace_bytes", sz),
+                ("c0", i32), ("c1", i32), ("c_in", i32),
+                ("n_img", i32), ("h_in", i32), ("w_in", i32), ("h_out", i32), ("w_out", i32),
+                ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32),
+                ("n_out", i32), ("dy_ld", i32), ("act_dtype", i32), ("accumulate", i32)]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp), ("dout", vp), ("dq", vp), ("dk", vp), ("dv", vp),
+                ("lse", vp), ("delta", vp), ("seg", vp),
+                ("ld_q", i32), ("ld_k", i32), ("ld_v", i32), ("ld_o", i32), ("ld_do", i32), ("ld_dq", i32), ("ld_dk", i32), ("ld_dv", i32),
+                ("heads", i32), ("head_dim", i32), ("n_seg", i32), ("max_q_len", i32), ("max_kv_len", i32), ("total_q_rows", i32),
+                ("stat_ld", i32), ("dtype", i32), ("scale", f32)]
+
+
+class _GroupNormBwd(C.Structure):
+    _fields_ = [("x0", vp), ("x1", vp), ("dy", vp), ("dx0", vp), ("dx1", vp), ("gamma", vp), ("beta", vp), ("stats", vp),
+                ("dgamma", vp), ("dbeta", vp), ("workspace", vp), ("workspace_bytes", sz),
+                ("n_img", i32), ("hw", i32), ("c0", i32), ("c1", i32), ("groups", i32), ("silu", i32), ("dtype", i32)]
+
+
+class _LayerNormBwd(C.Structure):
+    _fields_ = [("x", vp), ("dy", vp), ("dx", vp), ("gamma", vp), ("dgamma", vp), ("dbeta", vp), ("workspace", vp),
+                ("workspace_bytes", sz), ("rows", i32), ("c", i32), ("dtype", i32), ("eps", f32)]
+
+
+class _Colsum(C.Structure):
+    _fields_ = [("x", vp), ("dst", vp), ("workspace", vp), ("workspace_bytes", sz),
+                ("n_seg", i32), ("rows_per_seg", i32), ("n", i32), ("ld", i32), ("ld_dst", i32), ("per_seg", i32),
+                ("accumulate", i32), ("dtype", i32)]
+
+
+class _TrainEltwise(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("out", vp), ("rows", sz), ("op", i32), ("d", i32), ("a_dtype", i32), ("dtype", i32)]
+
+
+class _Resample(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("n_img", i32), ("h", i32), ("w", i32), ("c", i32), ("dtype", i32)]
+
+
+class _AddNoise(C.Structure):
+    _fields_ = [("x0", vp), ("noise", vp), ("coef", vp), ("dst", vp), ("img_map", vp),
+                ("n", i32), ("c", i32), ("hw", i32), ("dst_c", i32), ("dst_c_off", i32), ("dst_dtype", i32)]
+
+
+class _Mse(C.Structure):
+    _fields_ = [("pred", vp), ("noise", vp), ("tgt_img", vp), ("loss", vp), ("dpred", vp), ("workspace", vp),
+                ("n_tgt", i32), ("hw", i32), ("c", i32), ("accumulate", i32), ("dpred_c", i32), ("dpred_dtype", i32),
+                ("loss_scale", f32), ("grad_scale", f32)]
+
+
+class _Fill(C.Structure):
+    _fields_ = [("dst", vp), ("bytes", sz)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("igemm", IgemmDesc), ("groupnorm", _GroupNorm), ("layernorm", _LayerNorm), ("attention", _Attention),
                 ("temb", _Temb), ("eltwise", _Eltwise), ("ddim", _Ddim), ("advance", _Advance), ("layout", _Layout),
-                ("memcpy_", _Memcpy), ("rays", _Rays), ("posterior", _Posterior)]
+                ("memcpy_", _Memcpy), ("rays", _Rays), ("posterior", _Posterior),
+                ("wgrad", WgradDesc), ("attention_bwd", AttnBwdDesc), ("groupnorm_bwd", _GroupNormBwd),
+                ("layernorm_bwd", _LayerNormBwd), ("colsum", _Colsum), ("train_eltwise", _TrainEltwise), ("resample", _Resample),
+                ("add_noise", _AddNoise), ("mse", _Mse), ("fill", _Fill)]
 
 
 class Op(C.Structure):
@@ -104,10 +166,22 @@ SIGNATURES = {
     "mvldm_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(sz), C.c_char_p, C.c_int]),
     "mvldm_igemm_fwd": (C.c_int, [C.POINTER(IgemmDesc), vp]),
     "mvldm_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
-    "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 9 + [vp]),
-    "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp]),
+    "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
+    "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp, vp]),
     "mvldm_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
-    "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp]),
+    "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp, C.c_int, vp]),
+    "mvldm_igemm_wgrad": (C.c_int, [C.POINTER(WgradDesc), vp]),
+    "mvldm_colsum": (C.c_int, [vp, vp, vp, sz] + [C.c_int] * 8 + [vp]),
+    "mvldm_groupnorm_bwd": (C.c_int, [vp] * 10 + [C.c_int] * 7 + [vp, sz, vp]),
+    "mvldm_layernorm_bwd": (C.c_int, [vp] * 6 + [C.c_int, C.c_int, f32, C.c_int, vp, sz, vp]),
+    "mvldm_attention_bwd": (C.c_int, [C.POINTER(AttnBwdDesc), vp]),
+    "mvldm_train_eltwise": (C.c_int, [C.c_int, vp, vp, vp, sz, C.c_int, C.c_int, C.c_int, vp]),
+    "mvldm_pool2x2_sum": (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp]),
+    "mvldm_zero_insert2x": (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp]),
+    "mvldm_add_noise": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, vp]),
+    "mvldm_mse_loss": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, f32, vp, C.c_int, C.c_int, f32, vp, vp]),
+    "mvldm_grad_norm": (C.c_int, [vp, sz, vp, f32, vp, vp, vp]),
+    "mvldm_adamw_step": (C.c_int, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, C.c_int, f32, vp, vp]),
     "mvldm_timestep_embed_fwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mvldm_eltwise_fwd": (C.c_int, [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp]),
     "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),

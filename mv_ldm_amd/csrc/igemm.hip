@@ -970,7 +970,8 @@ template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce
 // ---- weight packing -------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_out,
-                                                          int c_in, int ksize, int c_pad, int n_pad, int k_pad, int geglu, int korder, int bk) {
+                                                          int c_in, int ksize, int c_pad, int n_pad, int k_pad, int geglu, int korder, int bk,
+                                                          int transpose, int c_off, int n_rows) {
     const size_t total = (size_t)n_pad * k_pad;
     const int taps = ksize * ksize;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -984,10 +985,16 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
             tap = k / c_pad;
             c = k - tap * c_pad;
         }
-        const int n = orig_col(np, n_out, geglu != 0);
         float v = 0.f;
-        if (n < n_out && tap < ksize * ksize && c < c_in)
-            v = src[((size_t)n * c_in + c) * (ksize * ksize) + tap];
+        if (transpose) {
+            // data-gradient weight: row np = input channel c_off + np, K channel `c` = OUTPUT channel, taps flipped
+            if (np < n_rows && tap < taps && c < n_out)
+                v = src[((size_t)c * c_in + (c_off + np)) * taps + (taps - 1 - tap)];
+        } else {
+            const int n = orig_col(np, n_out, geglu != 0);
+            if (n < n_out && tap < ksize * ksize && c < c_in)
+                v = src[((size_t)n * c_in + c) * (ksize * ksize) + tap];
+        }
         dst[idx] = from_f32<T>(v);
     }
 }
@@ -1352,17 +1359,22 @@ extern "C" size_t mvldm_igemm_workspace_bytes(const mvldm_igemm_desc* d) {
 }
 
 extern "C" int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksize, int c_pad, int n_pad,
-                                 int k_pad, int geglu, int k_order, int dst_dtype, mvldm_stream_t stream) {
+                                 int k_pad, int geglu, int k_order, int dst_dtype, int transpose, int c_off, int n_rows,
+                                 mvldm_stream_t stream) {
     const int bk = dst_dtype == MVLDM_F32 ? 32 : 64;
     MVLDM_REQUIRE(k_order == 0 || (k_order == 1 && c_pad % bk == 0), "pack_weight: k_order 1 needs c_pad %% %d == 0", bk);
-    MVLDM_REQUIRE(src && dst && c_pad >= c_in && n_pad >= n_out && k_pad >= ksize * ksize * c_pad, "pack_weight: bad dims");
+    if (transpose)
+        MVLDM_REQUIRE(src && dst && !geglu && c_pad >= n_out && c_off >= 0 && n_rows > 0 && c_off + n_rows <= c_in && n_pad >= n_rows &&
+                      k_pad >= ksize * ksize * c_pad, "pack_weight (transpose): bad dims");
+    else
+        MVLDM_REQUIRE(src && dst && c_pad >= c_in && n_pad >= n_out && k_pad >= ksize * ksize * c_pad, "pack_weight: bad dims");
     MVLDM_REQUIRE(!geglu || n_out % 64 == 0, "pack_weight: GEGLU needs n_out %% 64 == 0");
     const size_t total = (size_t)n_pad * k_pad;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
     return dispatch_dtype(dst_dtype, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
-                           reinterpret_cast<T*>(dst), n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu, k_order, bk);
+                           reinterpret_cast<T*>(dst), n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu, k_order, bk, transpose, c_off, n_rows);
         return check_launch();
     });
 }

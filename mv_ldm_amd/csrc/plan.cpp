@@ -25,6 +25,22 @@ int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c
 int ray_run(const float* extr, const float* intr, int n_cam, int h, int w, float* out_nchw, void* out_nhwc, int nhwc_c,
             int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, hipStream_t s);
 int posterior_run(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale, hipStream_t s);
+int wgrad_run(const mvldm_wgrad_desc& d, hipStream_t s);
+int attention_bwd_run(const mvldm_attn_bwd_desc& a, hipStream_t s);
+int groupnorm_bwd_run(const void* x0, const void* x1, const void* dy, void* dx0, void* dx1, const float* gamma, const float* beta,
+                      const float* stats, float* dgamma, float* dbeta, int n_img, int hw, int c0, int c1, int groups, int silu, int dtype,
+                      float* ws, size_t ws_bytes, hipStream_t s);
+int layernorm_bwd_run(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma, float* dbeta, int rows, int c, float eps, int dtype,
+                      float* ws, size_t ws_bytes, hipStream_t s);
+int colsum_run(const void* x, float* dst, float* ws, size_t ws_bytes, int n_seg, int rows_per_seg, int n, int ld, int ld_dst, int per_seg,
+               int accumulate, int dtype, hipStream_t s);
+int train_eltwise_run(int op, const void* a, const void* b, void* out, size_t rows, int d, int a_dtype, int dtype, hipStream_t s);
+int pool2x2_run(const void* du, void* dx, int n_img, int h, int w, int c, int dtype, hipStream_t s);
+int zero_insert_run(const void* x, void* out, int n_img, int h, int w, int c, int dtype, hipStream_t s);
+int add_noise_run(const float* x0, const float* noise, const float* coef, void* dst, int n, int c, int hw, int dst_c, int dst_c_off, int dst_dtype,
+                  const int32_t* img_map, hipStream_t s);
+int mse_run(const float* pred, const float* noise, const int32_t* tgt_img, int n_tgt, int hw, int c, float* loss, int accumulate, float loss_scale,
+            void* dpred, int dc, int dtype, float grad_scale, double* ws, hipStream_t s);
 int to_nchw_run(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off, int src_dtype, float scale,
                 float shift, int clamp01, hipStream_t s);
 
@@ -80,6 +96,49 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         case MVLDM_OP_POSTERIOR_SAMPLE: {
             const auto& q = op.u.posterior;
             return posterior_run(q.moments, q.noise, q.out, q.n, q.c, q.hw, q.scale, s);
+        }
+        case MVLDM_OP_WGRAD: return wgrad_run(op.u.wgrad, s);
+        case MVLDM_OP_ATTENTION_BWD: return attention_bwd_run(op.u.attention_bwd, s);
+        case MVLDM_OP_GROUPNORM_BWD: {
+            const auto& g = op.u.groupnorm_bwd;
+            return groupnorm_bwd_run(g.x0, g.x1, g.dy, g.dx0, g.dx1, g.gamma, g.beta, g.stats, g.dgamma, g.dbeta, g.n_img, g.hw, g.c0, g.c1,
+                                     g.groups, g.silu, g.dtype, g.workspace, g.workspace_bytes, s);
+        }
+        case MVLDM_OP_LAYERNORM_BWD: {
+            const auto& l = op.u.layernorm_bwd;
+            return layernorm_bwd_run(l.x, l.dy, l.dx, l.gamma, l.dgamma, l.dbeta, l.rows, l.c, l.eps, l.dtype, l.workspace, l.workspace_bytes, s);
+        }
+        case MVLDM_OP_COLSUM: {
+            const auto& c = op.u.colsum;
+            return colsum_run(c.x, c.dst, c.workspace, c.workspace_bytes, c.n_seg, c.rows_per_seg, c.n, c.ld, c.ld_dst, c.per_seg, c.accumulate,
+                              c.dtype, s);
+        }
+        case MVLDM_OP_TRAIN_ELTWISE: {
+            const auto& e = op.u.train_eltwise;
+            return train_eltwise_run(e.op, e.a, e.b, e.out, e.rows, e.d, e.a_dtype, e.dtype, s);
+        }
+        case MVLDM_OP_POOL2X2: {
+            const auto& r = op.u.resample;
+            return pool2x2_run(r.src, r.dst, r.n_img, r.h, r.w, r.c, r.dtype, s);
+        }
+        case MVLDM_OP_ZERO_INSERT: {
+            const auto& r = op.u.resample;
+            return zero_insert_run(r.src, r.dst, r.n_img, r.h, r.w, r.c, r.dtype, s);
+        }
+        case MVLDM_OP_ADD_NOISE: {
+            const auto& a = op.u.add_noise;
+            return add_noise_run(a.x0, a.noise, a.coef, a.dst, a.n, a.c, a.hw, a.dst_c, a.dst_c_off, a.dst_dtype, a.img_map, s);
+        }
+        case MVLDM_OP_MSE_LOSS: {
+            const auto& m = op.u.mse;
+            return mse_run(m.pred, m.noise, m.tgt_img, m.n_tgt, m.hw, m.c, m.loss, m.accumulate, m.loss_scale, m.dpred, m.dpred_c, m.dpred_dtype,
+                           m.grad_scale, m.workspace, s);
+        }
+        case MVLDM_OP_FILL_ZERO: {
+            const auto& f = op.u.fill;
+            if (f.bytes == 0) return MVLDM_OK;
+            MVLDM_CHECK_HIP(hipMemsetAsync(f.dst, 0, f.bytes, s));
+            return MVLDM_OK;
         }
         case MVLDM_OP_MEMCPY: {
             const auto& m = op.u.memcpy_;

@@ -57,11 +57,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 }
 // dst[seg][n] (ld_dst) = / += sum over chunks (per_seg), or dst[n] += sum over segments and chunks (!per_seg)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ dst, int n_seg,
-                                                            int nchunk, int n, int ld_dst, int per_seg, int accumulate) {
+                                                            int nchunk, int n, int n_valid, int ld_dst, int per_seg, int accumulate) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int total = per_seg ? n_seg * n : n;
+    const int total = per_seg ? n_seg * n_valid : n_valid;
     if (idx >= total) return;
-    const int seg = per_seg ? idx / n : 0, col = per_seg ? idx - seg * n : idx;
+    const int seg = per_seg ? idx / n_valid : 0, col = per_seg ? idx - seg * n_valid : idx;
     float t = 0.f;
     const int s0 = per_seg ? seg : 0, s1 = per_seg ? seg + 1 : n_seg;
     for (int sg = s0; sg < s1; ++sg)
@@ -141,6 +141,22 @@ template <typename T> __global__ __launch_bounds__(256) void pool2x2_kernel(cons
 #pragma unroll
         for (int k = 0; k < EPC; ++k) o.set(k, (a.get(k) + b.get(k)) + (d.get(k) + e.get(k)));
         store_chunk<T>(dx + p * c + ch, o);
+    }
+}
+
+// backward of a stride-2 subsampling: out[n][2i][2j][c] = x[n][i][j][c], zero at the odd positions
+template <typename T> __global__ __launch_bounds__(256) void zero_insert_kernel(const T* __restrict__ x, T* __restrict__ out, int n_img, int h, int w, int c) {
+    constexpr int EPC = Elt<T>::EPC;
+    const int cc = c / EPC;
+    const size_t total = (size_t)n_img * 2 * h * 2 * w * cc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ch = (int)(i % cc) * EPC;
+        const size_t pp = i / cc;
+        const int X = (int)(pp % (2 * w)), Y = (int)((pp / (2 * w)) % (2 * h)), img = (int)(pp / ((size_t)4 * w * h));
+        Chunk<T> v;
+        if ((X | Y) & 1) v.zero();
+        else v = load_chunk<T>(x + (((size_t)img * h + (Y >> 1)) * w + (X >> 1)) * c + ch);
+        store_chunk<T>(out + pp * c + ch, v);
     }
 }
 
@@ -269,7 +285,11 @@ int colsum_run(const void* x, float* dst, float* ws, size_t ws_bytes, int n_seg,
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
     if (n_seg == 0 || rows_per_seg == 0 || n == 0) return MVLDM_OK;
     MVLDM_REQUIRE(x && dst && ws, "colsum: null pointer");
-    MVLDM_REQUIRE(n % epc == 0 && ld % epc == 0 && ld >= n, "colsum: n=%d ld=%d must be multiples of %d", n, ld, epc);
+    // a column count that is not a whole number of 16-byte chunks (conv_out: 4) is summed over the padded width -- the
+    // buffer must then hold that padding (ld >= roundup(n)) -- and only the first n sums are written
+    const int n_valid = n;
+    n = (n + epc - 1) / epc * epc;
+    MVLDM_REQUIRE(ld % epc == 0 && ld >= n, "colsum: n=%d ld=%d (ld must be a multiple of %d and cover the padded width)", n_valid, ld, epc);
     int nchunk = std::max(1, std::min(std::min(rows_per_seg / 16, 64), (2048 + n_seg - 1) / n_seg));
     const int rpc = (rows_per_seg + nchunk - 1) / nchunk;
     nchunk = (rows_per_seg + rpc - 1) / rpc;
@@ -283,8 +303,8 @@ int colsum_run(const void* x, float* dst, float* ws, size_t ws_bytes, int n_seg,
         return check_launch();
     });
     if (rc) return rc;
-    const int total = per_seg ? n_seg * n : n;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, dst, n_seg, nchunk, n, ld_dst, per_seg, accumulate);
+    const int total = per_seg ? n_seg * n_valid : n_valid;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, dst, n_seg, nchunk, n, n_valid, ld_dst, per_seg, accumulate);
     return check_launch();
 }
 
@@ -330,6 +350,18 @@ int pool2x2_run(const void* du, void* dx, int n_img, int h, int w, int c, int dt
         using T = decltype(t);
         hipLaunchKernelGGL(pool2x2_kernel<T>, dim3(grid_for((size_t)n_img * h * w * (c / epc))), dim3(256), 0, s, reinterpret_cast<const T*>(du),
                            reinterpret_cast<T*>(dx), n_img, h, w, c);
+        return check_launch();
+    });
+}
+
+int zero_insert_run(const void* x, void* out, int n_img, int h, int w, int c, int dtype, hipStream_t s) {
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    if (n_img == 0 || h == 0 || w == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(x && out && c % epc == 0, "zero_insert2x: bad arguments");
+    return dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(zero_insert_kernel<T>, dim3(grid_for((size_t)n_img * 4 * h * w * (c / epc))), dim3(256), 0, s, reinterpret_cast<const T*>(x),
+                           reinterpret_cast<T*>(out), n_img, h, w, c);
         return check_launch();
     });
 }
@@ -395,6 +427,9 @@ extern "C" int mvldm_train_eltwise(int op, const void* a, const void* b, void* o
 }
 extern "C" int mvldm_pool2x2_sum(const void* du, void* dx, int n_img, int h, int w, int c, int dtype, mvldm_stream_t stream) {
     return pool2x2_run(du, dx, n_img, h, w, c, dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_zero_insert2x(const void* x, void* out, int n_img, int h, int w, int c, int dtype, mvldm_stream_t stream) {
+    return zero_insert_run(x, out, n_img, h, w, c, dtype, (hipStream_t)stream);
 }
 extern "C" int mvldm_add_noise(const float* x0, const float* noise, const float* coef, void* dst, int n, int c, int hw, int dst_c, int dst_c_off,
                                int dst_dtype, const int32_t* img_map, mvldm_stream_t stream) {

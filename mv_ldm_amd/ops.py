@@ -73,8 +73,28 @@ def block_k(dtype: torch.dtype) -> int:
     return 32 if dtype == torch.float32 else 64
 
 
+def pack_weight_t(w: torch.Tensor, dtype: torch.dtype, c_off: int = 0, n_rows: Optional[int] = None,
+                  out: Optional[torch.Tensor] = None) -> PackedWeight:
+    """the weight of the DATA-GRADIENT convolution of `w` (fp32 `[n_out, c_in, k, k]` / `[n_out, c_in]`): rows = input
+    channels [c_off, c_off + n_rows), K = (flipped tap, output channel).  Fed to the forward implicit GEMM with the
+    upstream gradient as its source, it yields dL/dx (stride-1 convs and Linears).  `out`: repack in place."""
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    n_out, c_in = w.shape[0], w.shape[1]
+    ksize = w.shape[2] if w.ndim == 4 else 1
+    n_rows = c_in - c_off if n_rows is None else n_rows
+    c_pad = _roundup(n_out, epc(dtype))
+    bk = block_k(dtype)
+    k_pad = _roundup(ksize * ksize * c_pad, bk)
+    n_pad = _roundup(n_rows, 64)
+    k_order = int(c_pad % bk == 0)
+    data = torch.zeros(n_pad, k_pad, dtype=dtype, device=w.device) if out is None else out
+    L.check(L.load().mvldm_pack_weight(w.data_ptr(), data.data_ptr(), n_out, c_in, ksize, c_pad, n_pad, k_pad, 0, k_order, dt(dtype),
+                                       1, c_off, n_rows, stream()))
+    return PackedWeight(data, n_rows, n_pad, k_pad, c_pad, ksize, False, k_order)
+
+
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None, geglu: bool = False,
-                c_split: Optional[int] = None) -> PackedWeight:
+                c_split: Optional[int] = None, out: Optional[torch.Tensor] = None) -> PackedWeight:
     """w: fp32 `[n_out, c_in, k, k]` (conv) or `[n_out, c_in]` (linear), on the GPU.  `c_split`: channel
     count of the first of two concatenated sources (decides whether the block-major K order applies)."""
     assert w.is_cuda, "pack_weight needs a device tensor (no CPU path)"
@@ -87,9 +107,9 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None
     k_pad = _roundup(ksize * ksize * c_pad, bk)
     n_pad = _roundup(n_out, 64)
     k_order = int(c_pad % bk == 0 and (c_split is None or c_split % bk == 0))
-    out = torch.empty(n_pad, k_pad, dtype=dtype, device=w.device)
+    out = torch.empty(n_pad, k_pad, dtype=dtype, device=w.device) if out is None else out
     L.check(L.load().mvldm_pack_weight(w.data_ptr(), out.data_ptr(), n_out, c_in, ksize, c_pad, n_pad, k_pad,
-                                       int(geglu), k_order, dt(dtype), stream()))
+                                       int(geglu), k_order, dt(dtype), 0, 0, n_out, stream()))
     return PackedWeight(out, n_out, n_pad, k_pad, c_pad, ksize, geglu, k_order)
 
 
@@ -188,8 +208,9 @@ def linear(x: torch.Tensor, pw: PackedWeight, bias=None, *, residual=None, epilo
 
 
 # ------------------------------------------------------------------------------------------ norms
-def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool, x2=None) -> torch.Tensor:
-    """x NHWC `[n, h, w, c]` (or `[n, hw, c]`); x2: optional second source concatenated along c."""
+def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool, x2=None, stats_out=None) -> torch.Tensor:
+    """x NHWC `[n, h, w, c]` (or `[n, hw, c]`); x2: optional second source concatenated along c.
+    stats_out: optional fp32 `[n, groups, 2]` receiving (mean, rstd) for the backward pass."""
     assert x.is_cuda and x.is_contiguous() and (x2 is None or x2.is_contiguous())
     n, c0 = x.shape[0], x.shape[-1]
     c1 = 0 if x2 is None else x2.shape[-1]
@@ -197,7 +218,7 @@ def groupnorm(x: torch.Tensor, gamma, beta, groups: int, eps: float, silu: bool,
     y = torch.empty(*x.shape[:-1], c0 + c1, dtype=x.dtype, device=x.device)
     ws = workspace(max(n, 1) * L.GN_MAX_CHUNKS * groups * 2 * 8, x.device, "gn")
     L.check(L.load().mvldm_groupnorm_fwd(x.data_ptr(), ptr(x2), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, hw, c0, c1,
-                                         groups, eps, int(silu), dt(x), ws.data_ptr(), stream()))
+                                         groups, eps, int(silu), dt(x), ws.data_ptr(), ptr(stats_out), stream()))
     return y
 
 
@@ -223,7 +244,7 @@ def make_segments(q_lens, kv_lens=None, device="cuda") -> torch.Tensor:
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, head_dim: int, seg: torch.Tensor,
-              max_q_len: int, scale: Optional[float] = None) -> torch.Tensor:
+              max_q_len: int, scale: Optional[float] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q/k/v: 2-D row-major views `[tokens, >= heads*head_dim]` (may be column slices of one fused
     projection: only the row stride is used).  Returns `[q_tokens, heads*head_dim]`."""
     assert q.is_cuda and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
@@ -231,7 +252,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, hea
     scale = head_dim ** -0.5 if scale is None else scale
     L.check(L.load().mvldm_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
                                          v.stride(0), out.stride(0), heads, head_dim, seg.data_ptr(), seg.shape[0],
-                                         max_q_len, scale, dt(q), stream()))
+                                         max_q_len, scale, dt(q), ptr(lse), 0 if lse is None else lse.stride(0), stream()))
     return out
 
 
@@ -322,3 +343,125 @@ def ddim_cfg_step(eps, x_t, cond_img, uncond_img, cfg_scale, coef, step_ptr, une
                                          0 if unet_in is None else unet_in.shape[-1],
                                          dt(unet_in) if unet_in is not None else L.F32, coef.shape[0], clip_range, stream()))
     return out
+
+
+# ------------------------------------------------------------------------------------------ training kernels
+def conv_wgrad(x, dy, grad, *, ksize, stride=1, pad=None, upsample=False, x2=None, c_in=None, accumulate=False, n_out=None) -> torch.Tensor:
+    """x (x2): NHWC forward input(s); dy: NHWC / `[m, ld]` upstream gradient (columns [0, n_out)); grad: fp32 PyTorch-layout
+    weight gradient `[n_out, c_in, k, k]` / `[n_out, c_in]`, written or accumulated in place."""
+    n, h, w, c0 = x.shape
+    c1 = 0 if x2 is None else x2.shape[-1]
+    pad = ksize // 2 if pad is None else pad
+    hs, ws_ = (2 * h, 2 * w) if upsample else (h, w)
+    ho, wo = (hs + 2 * pad - ksize) // stride + 1, (ws_ + 2 * pad - ksize) // stride + 1
+    n_out = grad.shape[0] if n_out is None else n_out
+    d = L.WgradDesc()
+    d.src0, d.src1, d.dy, d.grad = ptr(x), ptr(x2), ptr(dy), ptr(grad)
+    need = n_out * ksize * ksize * (c0 + c1) * 4
+    scratch = workspace(min(max(need * 8, 1 << 20), max(need, 512 << 20)), x.device, "wgrad")
+    d.workspace, d.workspace_bytes = scratch.data_ptr(), scratch.numel()
+    d.c0, d.c1, d.c_in = c0, c1, (c0 + c1) if c_in is None else c_in
+    d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, ho, wo
+    d.ksize, d.stride, d.pad, d.upsample = ksize, stride, pad, int(upsample)
+    d.n_out, d.dy_ld, d.act_dtype, d.accumulate = n_out, dy.stride(-2), dt(x), int(accumulate)
+    L.check(L.load().mvldm_igemm_wgrad(C.byref(d), stream()))
+    return grad
+
+
+def colsum(x2d, dst, rows_per_seg=None, per_seg=False, accumulate=False, n=None) -> torch.Tensor:
+    rows = x2d.shape[0]
+    n = x2d.shape[1] if n is None else n
+    rows_per_seg = rows if rows_per_seg is None else rows_per_seg
+    n_seg = rows // rows_per_seg
+    ws = workspace(max(n_seg * 64 * n * 4, 1 << 16), x2d.device, "colsum")
+    L.check(L.load().mvldm_colsum(x2d.data_ptr(), dst.data_ptr(), ws.data_ptr(), ws.numel(), n_seg, rows_per_seg, n, x2d.stride(0),
+                                  dst.stride(0) if dst.ndim == 2 else n, int(per_seg), int(accumulate), dt(x2d), stream()))
+    return dst
+
+
+def groupnorm_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, groups, silu, x2=None):
+    n, c0 = x.shape[0], x.shape[-1]
+    c1 = 0 if x2 is None else x2.shape[-1]
+    hw = math.prod(x.shape[1:-1])
+    dx, dx2 = torch.empty_like(x), (None if x2 is None else torch.empty_like(x2))
+    ws = workspace(n * L.GN_MAX_CHUNKS * (c0 + c1) * 2 * 4, x.device, "gnb")
+    L.check(L.load().mvldm_groupnorm_bwd(x.data_ptr(), ptr(x2), dy.data_ptr(), dx.data_ptr(), ptr(dx2), gamma.data_ptr(), beta.data_ptr(),
+                                         stats.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), n, hw, c0, c1, groups, int(silu), dt(x),
+                                         ws.data_ptr(), ws.numel(), stream()))
+    return dx, dx2
+
+
+def layernorm_bwd(x, dy, gamma, dgamma, dbeta, eps=1e-5):
+    c = x.shape[-1]
+    rows = x.numel() // c
+    dx = torch.empty_like(x)
+    ws = workspace(512 * c * 2 * 4, x.device, "lnb")
+    L.check(L.load().mvldm_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                         rows, c, eps, dt(x), ws.data_ptr(), ws.numel(), stream()))
+    return dx
+
+
+def attention_bwd(q, k, v, out, dout, lse, heads, head_dim, seg, max_q_len, max_kv_len, scale=None, dqkv=None):
+    """returns (dq, dk, dv) `[tokens, heads*head_dim]` (views of `dqkv` `[tokens, 3C]` when given)"""
+    C_ = heads * head_dim
+    if dqkv is None:
+        dq, dk, dv = (torch.empty(t.shape[0], C_, dtype=q.dtype, device=q.device) for t in (q, k, v))
+    else:
+        dq, dk, dv = dqkv[:, :C_], dqkv[:, C_:2 * C_], dqkv[:, 2 * C_:]
+    delta = torch.empty_like(lse)
+    d = L.AttnBwdDesc()
+    d.q, d.k, d.v, d.out, d.dout, d.dq, d.dk, d.dv = (t.data_ptr() for t in (q, k, v, out, dout, dq, dk, dv))
+    d.lse, d.delta, d.seg = lse.data_ptr(), delta.data_ptr(), seg.data_ptr()
+    d.ld_q, d.ld_k, d.ld_v, d.ld_o, d.ld_do, d.ld_dq, d.ld_dk, d.ld_dv = (t.stride(0) for t in (q, k, v, out, dout, dq, dk, dv))
+    d.heads, d.head_dim, d.n_seg, d.max_q_len, d.max_kv_len = heads, head_dim, seg.shape[0], max_q_len, max_kv_len
+    d.total_q_rows, d.stat_ld, d.dtype = q.shape[0], lse.stride(0), dt(q)
+    d.scale = head_dim ** -0.5 if scale is None else scale
+    L.check(L.load().mvldm_attention_bwd(C.byref(d), stream()))
+    return dq, dk, dv
+
+
+def train_eltwise(op: int, a, b, out, rows: int, d: int):
+    L.check(L.load().mvldm_train_eltwise(op, a.data_ptr(), ptr(b), out.data_ptr(), rows, d, dt(a), dt(out), stream()))
+    return out
+
+
+def silu_bwd(x, dy):
+    return train_eltwise(L.TE_SILU_BWD, x, dy, torch.empty_like(dy), 1, x.numel())
+
+
+def geglu_fwd(ag):
+    rows, d2 = ag.shape
+    return train_eltwise(L.TE_GEGLU_FWD, ag, None, torch.empty(rows, d2 // 2, dtype=ag.dtype, device=ag.device), rows, d2 // 2)
+
+
+def geglu_bwd(ag, dh):
+    rows, d2 = ag.shape
+    return train_eltwise(L.TE_GEGLU_BWD, ag, dh, torch.empty_like(ag), rows, d2 // 2)
+
+
+def pool2x2_sum(du):
+    n, h2, w2, c = du.shape
+    dx = torch.empty(n, h2 // 2, w2 // 2, c, dtype=du.dtype, device=du.device)
+    L.check(L.load().mvldm_pool2x2_sum(du.data_ptr(), dx.data_ptr(), n, h2 // 2, w2 // 2, c, dt(du), stream()))
+    return dx
+
+
+def zero_insert2x(x):
+    n, h, w, c = x.shape
+    out = torch.empty(n, 2 * h, 2 * w, c, dtype=x.dtype, device=x.device)
+    L.check(L.load().mvldm_zero_insert2x(x.data_ptr(), out.data_ptr(), n, h, w, c, dt(x), stream()))
+    return out
+
+
+def grad_norm(flat_grad, max_norm: float, norm_out=None, sumsq_in=None):
+    """norm_out fp32 [4]: [total norm, clip coefficient, this buffer's sum of squares, -]"""
+    norm_out = torch.zeros(4, dtype=torch.float32, device=flat_grad.device) if norm_out is None else norm_out
+    ws = workspace(1024 * 8, flat_grad.device, "norm")
+    L.check(L.load().mvldm_grad_norm(flat_grad.data_ptr(), flat_grad.numel(), ptr(sumsq_in), max_norm, norm_out.data_ptr(), ws.data_ptr(), stream()))
+    return norm_out
+
+
+def adamw_step(p, g, m, v, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, step=1, grad_scale=1.0, clip=None):
+    assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v))
+    L.check(L.load().mvldm_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1], eps,
+                                      weight_decay, step, grad_scale, ptr(clip), stream()))

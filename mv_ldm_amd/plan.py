@@ -191,7 +191,7 @@ class Builder:
                       name=name, row_bias=row_bias)
         return y.view(rows, -1)
 
-    def groupnorm(self, x, gamma, beta, groups, eps, silu, x2=None, name="groupnorm"):
+    def groupnorm(self, x, gamma, beta, groups, eps, silu, x2=None, name="groupnorm", stats_out=None):
         n, c0 = x.shape[0], x.shape[-1]
         c1 = 0 if x2 is None else x2.shape[-1]
         hw = x.numel() // (n * c0)
@@ -202,7 +202,8 @@ class Builder:
         g.x, g.x1, g.y, g.gamma, g.beta = ptr(x), ptr(x2), ptr(y), ptr(gamma), ptr(beta)
         g.stats_ws = self.gn_ws(n, groups).data_ptr()
         g.n_img, g.hw, g.c0, g.c1, g.groups, g.silu, g.dtype, g.eps = n, hw, c0, c1, groups, int(silu), dt(x), eps
-        self._emit(op, name, 0.0, 3.0 * y.numel() * y.element_size(), (x, x2, y, gamma, beta))
+        g.stats_out = ptr(stats_out)
+        self._emit(op, name, 0.0, 3.0 * y.numel() * y.element_size(), (x, x2, y, gamma, beta, stats_out))
         return y
 
     def layernorm(self, x, gamma, beta, eps=1e-5, name="layernorm"):
@@ -216,7 +217,7 @@ class Builder:
         self._emit(op, name, 0.0, 2.0 * y.numel() * y.element_size(), (x, y, gamma, beta))
         return y
 
-    def attention(self, q, k, v, heads, head_dim, seg, q_lens, kv_lens, scale=None, name="attention"):
+    def attention(self, q, k, v, heads, head_dim, seg, q_lens, kv_lens, scale=None, name="attention", lse=None):
         """q/k/v: 2-D views with unit column stride (may be slices of one fused projection)."""
         assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
         out = self.empty(q.shape[0], heads * head_dim, dtype=q.dtype)
@@ -227,10 +228,11 @@ class Builder:
         a.ld_q, a.ld_k, a.ld_v, a.ld_o = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
         a.heads, a.head_dim, a.n_seg, a.max_q_len, a.dtype = heads, head_dim, seg.shape[0], max(q_lens), dt(q)
         a.scale = head_dim ** -0.5 if scale is None else scale
+        a.lse, a.lse_ld = ptr(lse), (0 if lse is None else lse.stride(0))
         pairs = sum(ql * kl for ql, kl in zip(q_lens, kv_lens))
         es = q.element_size()
         nbytes = (sum(q_lens) * 2 + sum(kv_lens) * 2) * heads * head_dim * es
-        self._emit(op, name, 4.0 * pairs * heads * head_dim, nbytes, (q, k, v, out, seg))
+        self._emit(op, name, 4.0 * pairs * heads * head_dim, nbytes, (q, k, v, out, seg, lse))
         return out
 
     def timestep_embed(self, timesteps, freqs, dim, flip, dtype, name="time_proj"):

@@ -1,0 +1,1022 @@
+"""Training step of the multi-view denoiser on the HIP path: the counterpart of `DiffusionWrapper.training_step`
+(src/model/diffusion_wrapper.py:324-411), `configure_optimizers` (:1111-1122: AdamW lr 2e-5 + LinearLR warm-up,
+config/experiment/baseline.yaml:62-73) and of what Lightning's Trainer does around them in the reference run
+(src/main.py:119-136, config/main.yaml:82-84: `accumulate_grad_batches=2`, `gradient_clip_val=0.1`,
+`strategy=ddp_find_unused_parameters_true`).
+
+There is no autograd here: `TrainBuilder` records the forward walk of mvunet.py:90-208 op by op together with a closure
+that emits each op's backward kernels, `finalize()` replays the tape in reverse, and the whole micro-batch -- input
+assembly (add_noise, masks, ray grid), forward, MSE loss, backward -- becomes ONE C-side plan (`plan.Plan`).
+Gradient kernels (include/mvldm.h, "Training"):
+    data gradients   the forward implicit GEMM on transposed / flipped packs of the weights (`mvldm_pack_weight(transpose)`)
+    weight gradients `mvldm_igemm_wgrad` (pixel-reduction GEMM, deterministic split-K), fp32, straight into the flat buffer
+    norms            `mvldm_groupnorm_bwd`, `mvldm_layernorm_bwd`;  attention `mvldm_attention_bwd` (recompute from lse)
+    elementwise      SiLU / GEGLU backward, column sums for biases and the time-embedding rows
+Master weights, gradients and AdamW moments are fp32 in flat buffers (`FlatParams`); activations and activation
+gradients are in the compute dtype (bf16: the bench dtype; f32: the parity mode; the reference trains under fp16
+autocast WITH a loss scaler -- f16 activations gradients would need one here as well, so f16 is refused for training).
+Parameters that never enter the graph (the SD up-block transformers when `pretrained_from` is set, mvunet.py:178) are
+excluded statically instead of discovered per step (`find_unused_parameters`); parameters that enter it with an exactly
+zero gradient (cross-attention to the all-zero context, mvunet.py:124-128) stay in the optimizer -- AdamW's decoupled
+weight decay still moves them, as in the reference.
+Multi-GPU: `DistributedOptimizer` shards the flat buffers ZeRO-1 style -- bucketed reduce-scatter of the gradients in
+reverse-layer order on a side stream while the backward plan is still running, AdamW on the owned slices, all-gather of
+the updated weights (RCCL over xGMI via torch.distributed; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .ops import PackedWeight, dt, ptr
+from .plan import Builder, Plan
+
+
+# ================================================================================================ flat fp32 state
+class FlatParams:
+    """fp32 master parameters and gradients of the TRAINED part of a module in two flat device buffers; every
+    `nn.Parameter` becomes a view (`p.data`, `p.grad`), so state dicts / checkpoints keep working.  Order = module
+    registration order (what `parameters()` yields), offsets aligned to 16 bytes."""
+
+    def __init__(self, module: nn.Module, exclude: Sequence[nn.Parameter] = ()):
+        skip = {id(p) for p in exclude}
+        self.module = module
+        self.params = [p for p in module.parameters() if id(p) not in skip and p.requires_grad]
+        self.excluded = [p for p in module.parameters() if id(p) in skip]
+        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), "FlatParams needs fp32 parameters on the GPU"
+        self.offset: Dict[int, int] = {}
+        off = 0
+        for p in self.params:
+            self.offset[id(p)] = off
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        dev = self.params[0].device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p in self.params:
+                o, n = self.offset[id(p)], p.numel()
+                self.flat[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
+        self.epoch = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def bump(self):
+        """in-place kernel updates do not move torch's version counters: recorded INFERENCE plans key on this instead"""
+        self.epoch += 1
+        self.module._weights_epoch = self.epoch
+
+    def contiguous(self, ps: Sequence[nn.Parameter]) -> bool:
+        o = [self.offset[id(p)] for p in ps]
+        return all(o[i] + ps[i].numel() == o[i + 1] for i in range(len(ps) - 1))
+
+
+# ================================================================================================ tape builder
+def _key(t: torch.Tensor):
+    # (storage position, size): a [n, h, w, c] activation and its [n*h*w, c] token view are the same tensor
+    return (t.data_ptr(), t.numel())
+
+
+class TrainBuilder(Builder):
+    """records forward ops like `Builder` plus, per op, a closure that emits its backward ops"""
+
+    def __init__(self, device, dtype, flat: FlatParams, ws_bytes: int = 512 << 20):
+        assert dtype in (torch.float32, torch.bfloat16), "training runs in bf16 (fp32 accumulation / master weights) or f32"
+        super().__init__(device, dtype, record=True)
+        self.flat = flat
+        self.tape: List[Callable[[], None]] = []
+        self.grads: Dict[tuple, torch.Tensor] = {}
+        self.repack: List[Callable[[], None]] = []
+        self.touched: set = set()
+        self.grad_writes: List[Tuple[int, int]] = []      # (op index, flat offset) of every parameter-gradient write
+        self._wws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)      # wgrad slabs / colsum / norm partials
+        self.keep.append(self._wws)
+
+    def free(self, t):      # every activation is kept for the backward pass
+        return
+
+    # ---- gradient bookkeeping ----------------------------------------------------------------------
+    def grad_of(self, t):
+        return self.grads.get(_key(t))
+
+    def pop_grad(self, t):
+        g = self.grads.pop(_key(t), None)
+        return None if g is None else g.view(t.shape[:-1] + (g.numel() // max(math.prod(t.shape[:-1]), 1),))
+
+    def add_grad(self, t: Optional[torch.Tensor], g: torch.Tensor):
+        if t is None:
+            return
+        cur = self.grads.get(_key(t))
+        if cur is None:
+            self.grads[_key(t)] = g
+        else:
+            self._elt(L.TE_ADD, g, None, cur, 1, g.numel(), name="grad+=")
+
+    def _pgrad(self, p: nn.Parameter) -> torch.Tensor:
+        self.touched.add(id(p))
+        self.grad_writes.append((len(self.ops), self.flat.offset[id(p)]))
+        return p.grad
+
+    def touch(self, *ps):
+        """parameters that are in the graph but provably receive a zero gradient"""
+        for p in ps:
+            if p is not None:
+                self.touched.add(id(p))
+
+    # ---- raw op emitters (no tape) -------------------------------------------------------------------
+    def _elt(self, code, a, b, out, rows, d, name):
+        op = L.Op()
+        op.kind = L.OP_TRAIN_ELTWISE
+        e = op.u.train_eltwise
+        e.a, e.b, e.out, e.rows, e.op, e.d, e.a_dtype, e.dtype = ptr(a), ptr(b), ptr(out), rows, code, d, dt(a), dt(out)
+        self._emit(op, name, 0.0, (a.numel() + out.numel()) * out.element_size(), (a, b, out))
+        return out
+
+    def fill_zero(self, t, name="zero"):
+        op = L.Op()
+        op.kind = L.OP_FILL_ZERO
+        op.u.fill.dst, op.u.fill.bytes = ptr(t), t.numel() * t.element_size()
+        self._emit(op, name, 0.0, t.numel() * t.element_size(), (t,))
+
+    def _colsum(self, x2d, n, dst, ld_dst, rows_per_seg, per_seg, accumulate, name):
+        rows = x2d.shape[0]
+        op = L.Op()
+        op.kind = L.OP_COLSUM
+        c = op.u.colsum
+        c.x, c.dst, c.workspace, c.workspace_bytes = ptr(x2d), ptr(dst), ptr(self._wws), self._wws.numel()
+        c.n_seg, c.rows_per_seg, c.n, c.ld, c.ld_dst = rows // rows_per_seg, rows_per_seg, n, x2d.stride(0), ld_dst
+        c.per_seg, c.accumulate, c.dtype = int(per_seg), int(accumulate), dt(x2d)
+        self._emit(op, name, 0.0, x2d.numel() * x2d.element_size(), (x2d, dst))
+
+    def _wgrad(self, x, x2, dy2d, n_out, grad, geom, c_in, name):
+        n, h, w, c0 = x.shape
+        op = L.Op()
+        op.kind = L.OP_WGRAD
+        d = op.u.wgrad
+        d.src0, d.src1, d.dy, d.grad = ptr(x), ptr(x2), ptr(dy2d), ptr(grad)
+        d.workspace, d.workspace_bytes = ptr(self._wws), self._wws.numel()
+        d.c0, d.c1, d.c_in = c0, 0 if x2 is None else x2.shape[-1], c_in
+        d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, geom["ho"], geom["wo"]
+        d.ksize, d.stride, d.pad, d.upsample = geom["ksize"], geom["stride"], geom["pad"], int(geom["upsample"])
+        d.n_out, d.dy_ld, d.act_dtype, d.accumulate = n_out, dy2d.stride(0), dt(x), 1
+        m = n * geom["ho"] * geom["wo"]
+        k = geom["ksize"] ** 2 * (c0 + d.c1)
+        self._emit(op, name, 2.0 * m * n_out * k, (m * (n_out + k / geom["ksize"] ** 2)) * x.element_size() + n_out * k * 4.0, (x, x2, dy2d, grad))
+
+    def _as_act(self, g, name="cast"):
+        if g.dtype == self.dtype:
+            return g
+        return Builder.eltwise(self, g, L.ELT_COPY, out_dtype=self.dtype, name=name)
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def _weight2d(self, weights: Sequence[nn.Parameter]):
+        """fp32 [sum n_i, k] view (or persistent copy) of one or several stacked weights + its refresh closure"""
+        ws = list(weights)
+        for w in ws:
+            self.touched.add(id(w))
+        if len(ws) == 1:
+            return ws[0].data, None
+        if self.flat.contiguous(ws) and all(w.numel() % 4 == 0 for w in ws):
+            o = self.flat.offset[id(ws[0])]
+            tot = sum(w.numel() for w in ws)
+            return self.flat.flat[o:o + tot].view(sum(w.shape[0] for w in ws), *ws[0].shape[1:]), None
+        cat = torch.cat([w.detach() for w in ws], 0).contiguous()
+        rows = np.cumsum([0] + [w.shape[0] for w in ws])
+
+        def refresh():
+            for i, w in enumerate(ws):
+                cat[rows[i]:rows[i + 1]].copy_(w.detach())
+        return cat, refresh
+
+    def _packs(self, wsrc, refresh, need_t: bool, c_pad=None, c_split=None, t_splits=None):
+        """forward pack and (for the data gradient) transposed pack(s), refreshed in place when the weights change"""
+        pw = ops.pack_weight(wsrc, self.dtype, c_pad=c_pad, c_split=c_split)
+        pts = []
+        if need_t:
+            for (c_off, n_rows) in (t_splits or [(0, wsrc.shape[1])]):
+                pts.append((ops.pack_weight_t(wsrc, self.dtype, c_off, n_rows), c_off, n_rows))
+
+        def repack():
+            if refresh is not None:
+                refresh()
+            ops.pack_weight(wsrc, self.dtype, c_pad=c_pad, c_split=c_split, out=pw.data)
+            for pt, c_off, n_rows in pts:
+                ops.pack_weight_t(wsrc, self.dtype, c_off, n_rows, out=pt.data)
+        self.repack.append(repack)
+        self.keep.extend([wsrc, pw.data] + [p[0].data for p in pts])
+        return pw, [p[0] for p in pts]
+
+    def _bias(self, segments: Optional[Sequence[Sequence[nn.Parameter]]]):
+        """bias vector = concatenation over segments of the SUM of each segment's parameters (fp32)"""
+        if not segments:
+            return None
+        for sg in segments:
+            for p in sg:
+                self.touched.add(id(p))
+        if len(segments) == 1 and len(segments[0]) == 1:
+            return segments[0][0].data
+        sizes = [sg[0].numel() for sg in segments]
+        buf = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
+        offs = np.cumsum([0] + sizes)
+
+        def refresh():
+            for i, sg in enumerate(segments):
+                sl = buf[offs[i]:offs[i + 1]]
+                sl.copy_(sg[0].detach())
+                for extra in sg[1:]:       # fp32 add by the HIP elementwise kernel
+                    ops.train_eltwise(L.TE_ADD, extra.detach(), None, sl, 1, sl.numel())
+        refresh()
+        self.repack.append(refresh)
+        self.keep.append(buf)
+        return buf
+
+    # ---- differentiable ops ------------------------------------------------------------------------------
+    def t_linear(self, x, weights, biases=None, *, residual=None, out_dtype=None, x_grad=True, name="linear"):
+        """x [rows, c] -> [rows, sum n_i]; `weights`: parameters stacked along the output dim (fused QKV, all time_emb_proj);
+        `biases`: per weight a list of parameters whose SUM is that weight's bias (None: no bias)"""
+        rows, c = x.shape
+        wsrc, refresh = self._weight2d(weights)
+        w2d = wsrc.view(wsrc.shape[0], -1)
+        pw, pts = self._packs(w2d, refresh, x_grad)
+        bias = self._bias(biases)
+        y = Builder.linear(self, x, pw, bias, residual=residual, out_dtype=out_dtype, name=name)
+        n_i = [w.shape[0] for w in weights]
+
+        def backward():
+            dy = self.pop_grad(y)
+            if dy is None:
+                return
+            dy = self._as_act(dy, name + ".dy_cast")
+            with self.scope("bwd/" + name):
+                off = 0
+                for i, w in enumerate(weights):
+                    if biases:
+                        for p in biases[i]:
+                            self._colsum(dy[:, off:off + n_i[i]], n_i[i], self._pgrad(p), n_i[i], rows, False, True, "dbias")
+                    off += n_i[i]
+                geom = dict(ho=1, wo=1, ksize=1, stride=1, pad=0, upsample=False)
+                if len(weights) == 1 or self.flat.contiguous(list(weights)):
+                    self._wgrad(x.view(rows, 1, 1, c), None, dy, sum(n_i), self._pgrad(weights[0]), geom, c, "wgrad")
+                    for w in weights[1:]:
+                        self._pgrad(w)
+                else:
+                    off = 0
+                    for i, w in enumerate(weights):
+                        self._wgrad(x.view(rows, 1, 1, c), None, dy[:, off:off + n_i[i]], n_i[i], self._pgrad(w), geom, c, f"wgrad.{i}")
+                        off += n_i[i]
+                if x_grad:
+                    cur = self.pop_grad(x)
+                    dx = Builder.linear(self, dy, pts[0], None, residual=cur, name="dgrad")
+                    self.grads[_key(x)] = dx
+                if residual is not None:
+                    self.add_grad(residual, dy)
+        self.tape.append(backward)
+        return y
+
+    def t_conv(self, x, mod, *, x2=None, row_bias=None, residual=None, upsample=False, out_dtype=None, x_grad=True, name="conv"):
+        """mod: modules.Conv2d.  row_bias: (fp32 [n_img, C_out] view of the time-embedding projection, matching gradient view)"""
+        n, h, w, c0 = x.shape
+        c1 = 0 if x2 is None else x2.shape[-1]
+        weight, bias_p = mod.weight, mod.bias
+        ks, stride, pad = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+        assert not (upsample and stride != 1)
+        c_in = weight.shape[1]
+        self.touched.add(id(weight))
+        t_splits = [(0, c0)] if x2 is None else [(0, c0), (c0, c1)]
+        if c0 + c1 != c_in:     # conv_in: zero-padded input channels (no data gradient needed there)
+            assert not x_grad and x2 is None
+        pw, pts = self._packs(weight.data, None, x_grad, c_pad=c0 + c1, c_split=None if x2 is None else c0, t_splits=t_splits)
+        bias = self._bias([[bias_p]]) if bias_p is not None else None
+        rb = None if row_bias is None else row_bias[0]
+        y = Builder.conv(self, x, pw, bias, x2=x2, stride=stride, pad=pad, upsample=upsample, row_bias=rb, residual=residual,
+                         out_dtype=out_dtype, name=name)
+        ho, wo, co = y.shape[1], y.shape[2], weight.shape[0]
+        geom = dict(ho=ho, wo=wo, ksize=ks, stride=stride, pad=pad, upsample=upsample)
+
+        def backward():
+            dy = self.pop_grad(y)
+            if dy is None:
+                return
+            dy = self._as_act(dy, name + ".dy_cast")
+            dy2d = dy.view(n * ho * wo, dy.shape[-1])
+            with self.scope("bwd/" + name):
+                if bias_p is not None:
+                    self._colsum(dy2d, co, self._pgrad(bias_p), co, n * ho * wo, False, True, "dbias")
+                if row_bias is not None:      # gradient of the per-image time-embedding row: column sums per image
+                    self._colsum(dy2d, co, row_bias[1], row_bias[1].stride(0), ho * wo, True, False, "d_temb_row")
+                self._wgrad(x, x2, dy2d, co, self._pgrad(weight), geom, c_in, "wgrad")
+                if x_grad:
+                    src = dy
+                    if stride == 2:          # zero insertion turns the strided conv's data gradient into a stride-1 conv
+                        z = self.empty(n, 2 * ho, 2 * wo, dy.shape[-1])
+                        self._resample(L.OP_ZERO_INSERT, dy, z, n, ho, wo, dy.shape[-1], "zero_insert")
+                        src = z
+                        assert (2 * ho, 2 * wo) == (h, w), "stride-2 data gradient: even input sizes only"
+                    for (xs, pt) in zip((x, x2), pts):
+                        if xs is None:
+                            continue
+                        if upsample:         # gradient at the upsampled size, then 2x2 sums (backward of nearest-2x)
+                            du = Builder.conv(self, src, pt, None, name="dgrad_up")
+                            dx = self.empty(n, h, w, xs.shape[-1])
+                            self._resample(L.OP_POOL2X2, du, dx, n, h, w, xs.shape[-1], "pool2x2")
+                            self.add_grad(xs, dx)
+                        else:
+                            cur = self.pop_grad(xs)
+                            dx = Builder.conv(self, src, pt, None, residual=cur, name="dgrad")
+                            self.grads[_key(xs)] = dx
+                if residual is not None:
+                    self.add_grad(residual, dy)
+        self.tape.append(backward)
+        return y
+
+    def _resample(self, kind, src, dst, n, h, w, c, name):
+        op = L.Op()
+        op.kind = kind
+        r = op.u.resample
+        r.src, r.dst, r.n_img, r.h, r.w, r.c, r.dtype = ptr(src), ptr(dst), n, h, w, c, dt(src)
+        self._emit(op, name, 0.0, (src.numel() + dst.numel()) * src.element_size(), (src, dst))
+
+    def t_groupnorm(self, x, mod, silu, x2=None, name="groupnorm"):
+        n, c0 = x.shape[0], x.shape[-1]
+        c1 = 0 if x2 is None else x2.shape[-1]
+        hw = x.numel() // (n * c0)
+        gamma, beta = mod.weight, mod.bias
+        self.touch(gamma, beta)
+        stats = torch.zeros(n, mod.num_groups, 2, dtype=torch.float32, device=self.device)
+        self.keep.append(stats)
+        y = Builder.groupnorm(self, x, gamma.data, beta.data, mod.num_groups, mod.eps, silu, x2=x2, name=name, stats_out=stats)
+
+        def backward():
+            dy = self.pop_grad(y)
+            if dy is None:
+                return
+            dx, dx2 = self.empty(*x.shape), (None if x2 is None else self.empty(*x2.shape))
+            op = L.Op()
+            op.kind = L.OP_GROUPNORM_BWD
+            g = op.u.groupnorm_bwd
+            g.x0, g.x1, g.dy, g.dx0, g.dx1 = ptr(x), ptr(x2), ptr(dy), ptr(dx), ptr(dx2)
+            g.gamma, g.beta, g.stats, g.dgamma, g.dbeta = ptr(gamma.data), ptr(beta.data), ptr(stats), ptr(self._pgrad(gamma)), ptr(self._pgrad(beta))
+            g.workspace, g.workspace_bytes = ptr(self._wws), self._wws.numel()
+            g.n_img, g.hw, g.c0, g.c1, g.groups, g.silu, g.dtype = n, hw, c0, c1, mod.num_groups, int(silu), dt(x)
+            self._emit(op, "bwd/" + name, 0.0, 5.0 * dy.numel() * dy.element_size(), (x, x2, dy, dx, dx2, stats))
+            self.add_grad(x, dx)
+            self.add_grad(x2, dx2)
+        self.tape.append(backward)
+        return y
+
+    def t_layernorm(self, x, mod, name="layernorm"):
+        c = x.shape[-1]
+        gamma, beta = mod.weight, mod.bias
+        self.touch(gamma, beta)
+        y = Builder.layernorm(self, x, gamma.data, beta.data, mod.eps, name=name)
+
+        def backward():
+            dy = self.pop_grad(y)
+            if dy is None:
+                return
+            dx = self.empty(*x.shape)
+            op = L.Op()
+            op.kind = L.OP_LAYERNORM_BWD
+            l = op.u.layernorm_bwd
+            l.x, l.dy, l.dx, l.gamma, l.dgamma, l.dbeta = ptr(x), ptr(dy), ptr(dx), ptr(gamma.data), ptr(self._pgrad(gamma)), ptr(self._pgrad(beta))
+            l.workspace, l.workspace_bytes = ptr(self._wws), self._wws.numel()
+            l.rows, l.c, l.dtype, l.eps = x.numel() // c, c, dt(x), mod.eps
+            self._emit(op, "bwd/" + name, 0.0, 3.0 * dy.numel() * dy.element_size(), (x, dy, dx))
+            self.add_grad(x, dx)
+        self.tape.append(backward)
+        return y
+
+    def t_attention(self, qkv, heads, head_dim, seg, lens, name="sdpa"):
+        """self-attention on a fused projection qkv [M, 3C]"""
+        Cw = heads * head_dim
+        M = qkv.shape[0]
+        lse = torch.zeros(heads, M, dtype=torch.float32, device=self.device)
+        delta = torch.zeros(heads, M, dtype=torch.float32, device=self.device)
+        self.keep.extend([lse, delta])
+        out = Builder.attention(self, qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], heads, head_dim, seg, lens, lens, name=name, lse=lse)
+
+        def backward():
+            do = self.pop_grad(out)
+            if do is None:
+                return
+            dqkv = self.empty(M, 3 * Cw)
+            op = L.Op()
+            op.kind = L.OP_ATTENTION_BWD
+            d = op.u.attention_bwd
+            d.q, d.k, d.v, d.out, d.dout = ptr(qkv[:, :Cw]), ptr(qkv[:, Cw:2 * Cw]), ptr(qkv[:, 2 * Cw:]), ptr(out), ptr(do)
+            d.dq, d.dk, d.dv = ptr(dqkv[:, :Cw]), ptr(dqkv[:, Cw:2 * Cw]), ptr(dqkv[:, 2 * Cw:])
+            d.lse, d.delta, d.seg = ptr(lse), ptr(delta), ptr(seg)
+            d.ld_q = d.ld_k = d.ld_v = d.ld_dq = d.ld_dk = d.ld_dv = 3 * Cw
+            d.ld_o, d.ld_do = out.stride(0), do.stride(0)
+            d.heads, d.head_dim, d.n_seg, d.max_q_len, d.max_kv_len = heads, head_dim, seg.shape[0], max(lens), max(lens)
+            d.total_q_rows, d.stat_ld, d.dtype, d.scale = M, M, dt(qkv), head_dim ** -0.5
+            pairs = sum(l * l for l in lens)
+            self._emit(op, "bwd/" + name, 14.0 * pairs * Cw, 8.0 * M * Cw * qkv.element_size(), (qkv, out, do, dqkv, lse, delta, seg))
+            self.add_grad(qkv, dqkv)
+        self.tape.append(backward)
+        return out
+
+    def t_silu(self, x, out_dtype=None, name="silu"):
+        y = Builder.eltwise(self, x, L.ELT_SILU, out_dtype=out_dtype, name=name)
+
+        def backward():
+            dy = self.pop_grad(y)
+            if dy is None:
+                return
+            dy = self._as_act(dy)
+            dx = self.empty(*x.shape)
+            self._elt(L.TE_SILU_BWD, x, dy, dx, 1, x.numel(), "bwd/" + name)
+            self.add_grad(x, dx)
+        self.tape.append(backward)
+        return y
+
+    def t_geglu(self, ag, name="geglu"):
+        rows, d2 = ag.shape
+        h = self.empty(rows, d2 // 2)
+        self._elt(L.TE_GEGLU_FWD, ag, None, h, rows, d2 // 2, name)
+
+        def backward():
+            dh = self.pop_grad(h)
+            if dh is None:
+                return
+            dag = self.empty(rows, d2)
+            self._elt(L.TE_GEGLU_BWD, ag, dh, dag, rows, d2 // 2, "bwd/" + name)
+            self.add_grad(ag, dag)
+        self.tape.append(backward)
+        return h
+
+    def emit_backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+# ================================================================================================ the network walk
+def _segments(b: Builder, lens):
+    from .modules import _segments as seg_of
+    return seg_of(b, lens)
+
+
+def _t_resnet(b: TrainBuilder, r, x, skip, tproj, name):
+    with b.scope(name):
+        g1 = b.t_groupnorm(x, r.norm1, True, x2=skip, name="norm1+silu")
+        h = b.t_conv(g1, r.conv1, row_bias=tproj, name="conv1")
+        g2 = b.t_groupnorm(h, r.norm2, True, name="norm2+silu")
+        if r.conv_shortcut is not None:
+            sc = b.t_conv(x, r.conv_shortcut, x2=skip, name="conv_shortcut")
+        else:
+            assert skip is None
+            sc = x
+        return b.t_conv(g2, r.conv2, residual=sc, name="conv2")
+
+
+def _t_ff(b: TrainBuilder, ff, xn, residual, name="ff"):
+    p = ff.net[0].proj
+    ag = b.t_linear(xn, [p.weight], [[p.bias]], name=name + ".proj")
+    h = b.t_geglu(ag, name=name + ".geglu")
+    o = ff.net[2]
+    return b.t_linear(h, [o.weight], [[o.bias]], residual=residual, name=name + ".out")
+
+
+def _t_self_attn(b: TrainBuilder, attn, xn, residual, lens, extra_bias=None, name="attn"):
+    qkv = b.t_linear(xn, [attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], None if attn.to_q.bias is None else
+                     [[attn.to_q.bias], [attn.to_k.bias], [attn.to_v.bias]], name=name + ".to_qkv")
+    a = b.t_attention(qkv, attn.heads, attn.dim_head, _segments(b, lens), lens, name=name + ".sdpa")
+    o = attn.to_out[0]
+    biases = [o.bias] + ([extra_bias] if extra_bias is not None else [])
+    return b.t_linear(a, [o.weight], [biases], residual=residual, name=name + ".to_out")
+
+
+def _proj(b: TrainBuilder, mod, x2d, residual=None, name="proj"):
+    """Linear, or a 1x1 Conv2d applied to token rows"""
+    return b.t_linear(x2d, [mod.weight], [[mod.bias]] if mod.bias is not None else None, residual=residual, name=name)
+
+
+def _t_transformer2d(b: TrainBuilder, t, x, name):
+    """diffusers Transformer2DModel with the all-zero context of mvunet.py:124-128: cross-attention == its output bias"""
+    n, h, w, c = x.shape
+    with b.scope(name):
+        g = b.t_groupnorm(x, t.norm, False, name="norm")
+        hs = _proj(b, t.proj_in, g.view(n * h * w, c), name="proj_in")
+        for i, blk in enumerate(t.transformer_blocks):
+            with b.scope(f"transformer_blocks.{i}"):
+                lens = [h * w] * n
+                n1 = b.t_layernorm(hs, blk.norm1, name="norm1")
+                a2 = blk.attn2
+                h1 = _t_self_attn(b, blk.attn1, n1, hs, lens, extra_bias=a2.to_out[0].bias, name="attn1")
+                # in the graph with an exactly zero gradient (k = v = 0): decayed by AdamW like in the reference
+                b.touch(a2.to_q.weight, a2.to_k.weight, a2.to_v.weight, a2.to_out[0].weight, blk.norm2.weight, blk.norm2.bias,
+                        a2.to_q.bias, a2.to_k.bias, a2.to_v.bias)
+                n3 = b.t_layernorm(h1, blk.norm3, name="norm3")
+                hs = _t_ff(b, blk.ff, n3, h1)
+        out = _proj(b, t.proj_out, hs, residual=x.view(n * h * w, c), name="proj_out")
+        return out.view(n, h, w, c)
+
+
+def _t_mv_block(b: TrainBuilder, m, x, groups, name):
+    """SpatialTransformer3D (mvdream/attention.py:371-439)"""
+    n, h, w, c = x.shape
+    tokens = h * w
+    with b.scope(name):
+        g = b.t_groupnorm(x, m.norm, False, name="norm")
+        hs = _proj(b, m.proj_in, g.view(n * tokens, c), name="proj_in")
+        for i, blk in enumerate(m.transformer_blocks):
+            with b.scope(f"transformer_blocks.{i}"):
+                scene_lens, view_lens = [v * tokens for v in groups], [tokens] * sum(groups)
+                n1 = b.t_layernorm(hs, blk.norm1, name="norm1")
+                h1 = _t_self_attn(b, blk.attn1, n1, hs, scene_lens, name="attn1_3d")
+                n2 = b.t_layernorm(h1, blk.norm2, name="norm2")
+                h2 = _t_self_attn(b, blk.attn2, n2, h1, view_lens, name="attn2_view")
+                n3 = b.t_layernorm(h2, blk.norm3, name="norm3")
+                hs = _t_ff(b, blk.ff, n3, h2)
+        out = _proj(b, m.proj_out, hs, residual=x.view(n * tokens, c), name="proj_out")
+        return out.view(n, h, w, c)
+
+
+def emit_unet_train(b: TrainBuilder, den, x_in, timesteps, groups):
+    """the walk of MultiViewUNet.forward (mvunet.py:90-208) on the tape builder; returns eps fp32 NHWC [n_img, h, w, out]"""
+    u = den.unet
+    n_img = x_in.shape[0]
+    with b.scope("time"):
+        t_emb = u.time_proj.emit(b, timesteps, dtype=b.dtype)
+        te = u.time_embedding
+        l1 = b.t_linear(t_emb, [te.linear_1.weight], [[te.linear_1.bias]], x_grad=False, name="time_embedding.linear_1")
+        a1 = b.t_silu(l1, name="time_embedding.act")
+        emb = b.t_linear(a1, [te.linear_2.weight], [[te.linear_2.bias]], name="time_embedding.linear_2")
+        emb_act = b.t_silu(emb, name="temb_silu")
+        rs = den._resnets_in_order()
+        allp = b.t_linear(emb_act, [r.time_emb_proj.weight for r in rs], [[r.time_emb_proj.bias] for r in rs], out_dtype=torch.float32,
+                          name="time_emb_proj[all]")
+        d_allp = torch.zeros_like(allp)
+        b.keep.append(d_allp)
+        b.grads[_key(allp)] = d_allp
+        tproj, off = {}, 0
+        for r in rs:
+            tproj[id(r)] = (allp[:, off:off + r.out_channels], d_allp[:, off:off + r.out_channels])
+            off += r.out_channels
+    h = b.t_conv(x_in, u.conv_in, x_grad=False, name="conv_in")
+    skips = [h]
+    for lvl, blk in enumerate(u.down_blocks):
+        has_attn = getattr(blk, "has_cross_attention", False)
+        for i, r in enumerate(blk.resnets):
+            h = _t_resnet(b, r, h, None, tproj[id(r)], f"down{lvl}.resnets.{i}")
+            if has_attn:
+                h = _t_transformer2d(b, blk.attentions[i], h, f"down{lvl}.attentions.{i}")
+            skips.append(h)
+        if h.shape[1] <= 32 and h.shape[2] <= 32 and den.cfg.encoder_conditioning:
+            h = _t_mv_block(b, den.cross_attn_blocks_encoder[lvl], h, groups, f"mv_encoder.{lvl}")
+        if blk.downsamplers is not None:
+            for d in blk.downsamplers:
+                h = b.t_conv(h, d.conv, name=f"down{lvl}.downsample")
+            skips.append(h)
+    mid = u.mid_block
+    h = _t_resnet(b, mid.resnets[0], h, None, tproj[id(mid.resnets[0])], "mid.resnets.0")
+    for i, (attn, r) in enumerate(zip(mid.attentions, mid.resnets[1:])):
+        h = _t_transformer2d(b, attn, h, f"mid.attentions.{i}")
+        h = _t_resnet(b, r, h, None, tproj[id(r)], f"mid.resnets.{i + 1}")
+    if den.cfg.mid_conditioning:
+        h = _t_mv_block(b, den.cross_attn_blocks_mid[0], h, groups, "mv_mid")
+    for lvl, blk in enumerate(u.up_blocks):
+        has_attn = getattr(blk, "has_cross_attention", False) and den.pretrained_from is None
+        for i, r in enumerate(blk.resnets):
+            h = _t_resnet(b, r, h, skips.pop(), tproj[id(r)], f"up{lvl}.resnets.{i}")
+            if has_attn:
+                h = _t_transformer2d(b, blk.attentions[i], h, f"up{lvl}.attentions.{i}")
+        if h.shape[1] <= 32 and h.shape[2] <= 32 and den.cfg.decoder_conditioning:
+            h = _t_mv_block(b, den.cross_attn_blocks_decoder[lvl], h, groups, f"mv_decoder.{lvl}")
+        if blk.upsamplers is not None:
+            for up in blk.upsamplers:
+                h = b.t_conv(h, up.conv, upsample=True, name=f"up{lvl}.upsample")
+    g = b.t_groupnorm(h, u.conv_norm_out, True, name="conv_norm_out+silu")
+    return b.t_conv(g, u.conv_out, out_dtype=torch.float32, name="conv_out")
+
+
+def never_trained(den) -> List[nn.Parameter]:
+    """parameters that never enter the training graph: the SD up-block transformers when the UNet comes from a
+    pretrained SD checkpoint (mvunet.py:178: `self.pretrained_from is None` gates them)"""
+    out = []
+    if den.pretrained_from is not None:
+        for blk in den.unet.up_blocks:
+            if getattr(blk, "has_cross_attention", False):
+                out += list(blk.attentions.parameters())
+    return out
+
+
+# ================================================================================================ one micro-batch plan
+class TrainPlan:
+    """input assembly + forward + loss + backward of ONE micro-batch shape as a C-side plan.
+    shape = (b scenes, v_c context views [0 = unconditional], v_t target views, hl, wl)."""
+
+    def __init__(self, den, flat: FlatParams, b: int, v_c: int, v_t: int, hl: int, wl: int, dtype, loss_scale: float = 1.0,
+                 grad_scale: float = 1.0, graph: bool = False):
+        dev = flat.flat.device
+        self.shape = (b, v_c, v_t, hl, wl)
+        v = v_c + v_t
+        n_img, lc = b * v, den.out_channels
+        e = ops.epc(dtype)
+        c_pad = (den.in_channels + e - 1) // e * e
+        bld = TrainBuilder(dev, dtype, flat)
+        z = lambda *s, dt_=torch.float32: torch.zeros(*s, dtype=dt_, device=dev)
+        # ---- inputs staged by the host (copies), assembled by HIP kernels (diffusion_wrapper.py:362-398) ----
+        self.latents = z(n_img, lc, hl, wl)            # first_stage_encode of [context | target] views, per scene
+        self.noise = z(b * v_t, lc, hl, wl)            # target_noise
+        self.coef = z(n_img, 2)                        # (sqrt(a_t), sqrt(1 - a_t)); context rows: (1, 0)
+        self.timesteps = torch.zeros(n_img, dtype=torch.int64, device=dev)
+        self.extr, self.intr = z(n_img, 4, 4), z(n_img, 3, 3)
+        self.loss = z(1)
+        ones = torch.ones(b * v_t, 1, hl, wl, dtype=torch.float32, device=dev)
+        unet_in = z(n_img, hl, wl, c_pad, dt_=dtype)
+        tgt_img = torch.tensor([s * v + v_c + j for s in range(b) for j in range(v_t)], dtype=torch.int32, device=dev)
+        # the noise buffer holds target views only; add_noise walks all images with a per-image coefficient pair, so the
+        # context rows read a zero "noise" with coefficient (1, 0): give it a full-size view
+        self.noise_all = z(n_img, lc, hl, wl)
+        with bld.scope("inputs"):
+            op = L.Op()
+            op.kind = L.OP_ADD_NOISE
+            a = op.u.add_noise
+            a.x0, a.noise, a.coef, a.dst, a.img_map = ptr(self.latents), ptr(self.noise_all), ptr(self.coef), ptr(unet_in), None
+            a.n, a.c, a.hw, a.dst_c, a.dst_c_off, a.dst_dtype = n_img, lc, hl * wl, c_pad, 0, dt(unet_in)
+            bld._emit(op, "add_noise -> latent channels", 0.0, 3.0 * self.latents.numel() * 4, (self.latents, self.noise_all, self.coef, unet_in))
+            bld.nchw_to_nhwc(ones, unet_in, lc, img_map=tgt_img, name="target mask")
+            bld.ray_encode(self.extr, self.intr, hl, wl, unet_in, lc + 1, name="ray grid")
+        with bld.scope("unet"):
+            eps = emit_unet_train(bld, den, unet_in, self.timesteps, [v] * b)
+        dc = (lc + e - 1) // e * e
+        d_eps = z(n_img, hl, wl, dc, dt_=dtype)
+        ws = torch.zeros(256, dtype=torch.float64, device=dev)
+        bld.fill_zero(d_eps, "d_eps = 0")
+        op = L.Op()
+        op.kind = L.OP_MSE_LOSS
+        m = op.u.mse
+        m.pred, m.noise, m.tgt_img, m.loss, m.dpred, m.workspace = ptr(eps), ptr(self.noise), ptr(tgt_img), ptr(self.loss), ptr(d_eps), ptr(ws)
+        m.n_tgt, m.hw, m.c, m.accumulate, m.dpred_c, m.dpred_dtype = b * v_t, hl * wl, lc, 1, dc, dt(d_eps)
+        m.loss_scale, m.grad_scale = loss_scale, grad_scale
+        bld._emit(op, "mse_loss", 0.0, eps.numel() * 8.0, (eps, self.noise, tgt_img, self.loss, d_eps, ws))
+        self.n_forward_ops = len(bld.ops)
+        bld.grads[_key(eps)] = d_eps
+        with bld.scope("backward"):
+            bld.emit_backward()
+        assert not bld.tape
+        self.eps, self.unet_in, self.tgt_img = eps, unet_in, tgt_img
+        self.touched, self.grad_writes, self.repack = bld.touched, bld.grad_writes, bld.repack
+        self.plan: Plan = bld.finalize(autotune=False)
+        self.graph = graph
+        if graph:
+            self.plan.capture()
+            self.loss.zero_()
+            flat.zero_grad()
+
+    def refresh_weights(self):
+        for fn in self.repack:
+            fn()
+
+    def run(self, first: int = 0, last: Optional[int] = None):
+        if self.graph and first == 0 and last is None:
+            self.plan.replay()
+        else:
+            self.plan.run(first, last)
+
+
+# ================================================================================================ optimizer
+@dataclass
+class OptimizerCfg:
+    """src/model/diffusion_wrapper.py:44-56 + config/experiment/baseline.yaml:62-73"""
+    name: str = "AdamW"
+    lr: float = 2.0e-5
+    scale_lr: bool = False
+    kwargs: Optional[dict] = None                 # forwarded like `getattr(optim, name)(params, lr=lr, **kwargs)`: betas, eps, weight_decay
+    scheduler: Optional[dict] = field(default_factory=lambda: {"name": "LinearLR", "frequency": 1, "interval": "step",
+                                                               "kwargs": {"start_factor": 5e-4, "total_iters": 200}})
+
+
+def linear_lr_factor(step: int, start_factor: float = 1.0 / 3, end_factor: float = 1.0, total_iters: int = 5) -> float:
+    """torch.optim.lr_scheduler.LinearLR in closed form: the factor in force after `step` scheduler steps"""
+    return start_factor + (end_factor - start_factor) * min(step, total_iters) / total_iters
+
+
+class DistributedOptimizer:
+    """AdamW over the flat buffers, sharded ZeRO-1 style over `world` ranks.
+
+    The flat gradient is cut into buckets (contiguous ranges, sizes a multiple of `world` x 4 floats); bucket k is
+    reduce-scattered as soon as the backward plan has produced it (buckets complete from the END of the buffer: the
+    backward pass visits layers in reverse), rank r keeps the r-th slice of every bucket, updates the matching slice of
+    the master weights with its slice of the moments, and the slices are all-gathered back.  world = 1: no collectives.
+    `update` / `sumsq` default to the HIP kernels; the CPU tests inject torch implementations (there is no CPU product path)."""
+
+    def __init__(self, flat: FlatParams, cfg: OptimizerCfg = None, world: int = 1, rank: int = 0, group=None,
+                 bucket_bytes: int = 256 << 20, max_norm: float = 0.1, update=None, sumsq=None, clip=None):
+        cfg = cfg or OptimizerCfg()
+        if cfg.name != "AdamW":
+            raise NotImplementedError(f"optimizer {cfg.name}: the released config trains with AdamW (baseline.yaml:63)")
+        kw = dict(cfg.kwargs or {})
+        self.lr0, self.betas = cfg.lr, tuple(kw.get("betas", (0.9, 0.999)))
+        self.eps, self.weight_decay = kw.get("eps", 1e-8), kw.get("weight_decay", 1e-2)
+        self.sched = cfg.scheduler
+        if self.sched is not None and self.sched.get("name") != "LinearLR":
+            raise NotImplementedError(f"lr scheduler {self.sched.get('name')}: the released config uses LinearLR (baseline.yaml:68)")
+        self.flat, self.world, self.rank, self.group, self.max_norm = flat, world, rank, group, max_norm
+        self.buckets = make_buckets(flat.numel, world, bucket_bytes // 4)
+        self.step_count = 0          # optimizer steps taken == scheduler steps taken
+        dev = flat.flat.device
+        self.owned = [(a + rank * (b - a) // world, a + (rank + 1) * (b - a) // world) for a, b in self.buckets]
+        n_own = sum(b - a for a, b in self.owned)
+        self.exp_avg = torch.zeros(n_own, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n_own, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._update, self._sumsq, self._clip = update or _hip_adamw, sumsq or _hip_sumsq, clip or _hip_clip
+        self._pending = []
+
+    # ---- learning rate (LinearLR: factor after `step_count` scheduler steps) ----
+    def lr(self) -> float:
+        if self.sched is None:
+            return self.lr0
+        return self.lr0 * linear_lr_factor(self.step_count, **self.sched.get("kwargs", {}))
+
+    # ---- gradient exchange ----
+    def reduce_bucket(self, k: int, stream=None):
+        """reduce-scatter bucket k of the flat gradient (sum over ranks; the loss scale already carries 1/world)"""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        a, b = self.buckets[k]
+        oa, ob = self.owned[k]
+        g = self.flat.grad
+        if dist.get_backend(self.group) == "gloo":      # CPU tests: gloo has no reduce-scatter; the owned slice of an all-reduce is the same thing
+            self._pending.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:                                           # RCCL, in place: recvbuff == sendbuff + rank * recvcount
+            self._pending.append(dist.reduce_scatter_tensor(g[oa:ob], g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def step(self):
+        """clip (global norm over ALL ranks' slices) + AdamW on the owned slices + all-gather of the weights"""
+        self.wait()
+        g, p = self.flat.grad, self.flat.flat
+        own_sq = torch.zeros(1, dtype=torch.float32, device=g.device)
+        for oa, ob in self.owned:
+            own_sq += self._sumsq(g[oa:ob])                 # (a handful of scalars: bookkeeping, not the data path)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(own_sq, op=dist.ReduceOp.SUM, group=self.group)
+        self._clip(own_sq, self.max_norm or 0.0, self.norm)     # norm[0] = total norm, norm[1] = clip coefficient
+        total = self.norm[0]
+        self.step_count += 1
+        lr, off = self._lr_for_step(), 0
+        for oa, ob in self.owned:
+            n = ob - oa
+            self._update(p[oa:ob], g[oa:ob], self.exp_avg[off:off + n], self.exp_avg_sq[off:off + n], lr, self.betas, self.eps,
+                         self.weight_decay, self.step_count, self.norm)
+            off += n
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.get_backend(self.group) == "gloo":
+                for (a, b) in self.buckets:
+                    n = (b - a) // self.world
+                    dist.all_gather([p[a + r * n:a + (r + 1) * n] for r in range(self.world)], p[a + self.rank * n:a + (self.rank + 1) * n].clone(),
+                                    group=self.group)
+            else:                                       # in place: sendbuff == recvbuff + rank * sendcount
+                works = [dist.all_gather_into_tensor(p[a:b], p[oa:ob], group=self.group, async_op=True)
+                         for (a, b), (oa, ob) in zip(self.buckets, self.owned)]
+                for w in works:
+                    w.wait()
+        self.flat.bump()
+        return float(total)
+
+    def _lr_for_step(self) -> float:
+        # the factor in force for optimizer step t (1-based) is the one after t-1 scheduler steps
+        if self.sched is None:
+            return self.lr0
+        return self.lr0 * linear_lr_factor(self.step_count - 1, **self.sched.get("kwargs", {}))
+
+
+def make_buckets(numel: int, world: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    """contiguous [a, b) ranges covering [0, numel), every length a multiple of world*4 (numel is padded by the caller's
+    buffers: FlatParams aligns to 4; the last bucket absorbs the remainder and is padded virtually up to the quantum)"""
+    q = world * 4
+    bucket_elems = max(q, bucket_elems // q * q)
+    out, a = [], 0
+    while a < numel:
+        b = min(numel, a + bucket_elems)
+        out.append((a, b))
+        a = b
+    if out and (out[-1][1] - out[-1][0]) % q:
+        raise ValueError(f"flat buffer of {numel} elements is not a multiple of world*4 = {q}: pad FlatParams (pad_to=world*4)")
+    return out
+
+
+def _hip_sumsq(g: torch.Tensor) -> torch.Tensor:
+    n = ops.grad_norm(g, 0.0)
+    return n[2:3].clone()
+
+
+def _hip_clip(sumsq: torch.Tensor, max_norm: float, norm_out: torch.Tensor):
+    """total norm + clip coefficient from an (all-reduced) sum of squares: the HIP kernel with an empty buffer"""
+    ws = ops.workspace(1024 * 8, sumsq.device, "norm")
+    L.check(L.load().mvldm_grad_norm(sumsq.data_ptr(), 0, sumsq.data_ptr(), max_norm, norm_out.data_ptr(), ws.data_ptr(), ops.stream()))
+
+
+def _hip_adamw(p, g, m, v, lr, betas, eps, wd, step, norm):
+    ops.adamw_step(p, g, m, v, lr, betas, eps, wd, step, 1.0, norm)
+
+
+# ================================================================================================ the training wrapper
+@dataclass
+class TrainCfg:
+    cfg_train: bool = True               # config/main.yaml:33,67: 10 % unconditional steps
+    accumulate_grad_batches: int = 2     # config/main.yaml:84
+    gradient_clip_val: float = 0.1       # config/main.yaml:82
+    num_train_timesteps: int = 1000      # config/model/scheduler/ddim.yaml:4
+
+
+class MVLDMTrainer:
+    """`DiffusionWrapper` + the Lightning loop for the training path: `training_step(batch)` per micro-batch, an optimizer
+    step every `accumulate_grad_batches` micro-batches."""
+
+    def __init__(self, denoiser, autoencoder, scheduler, optimizer_cfg: OptimizerCfg = None, train_cfg: TrainCfg = None,
+                 dtype=torch.bfloat16, world: int = 1, rank: int = 0, group=None, graph: bool = False, bucket_bytes: int = 256 << 20):
+        self.denoiser, self.autoencoder, self.scheduler = denoiser, autoencoder, scheduler
+        self.cfg = train_cfg or TrainCfg()
+        self.dtype, self.world, self.rank, self.graph = dtype, world, rank, graph
+        for p in autoencoder.parameters():           # freeze.autoencoder = true (config/main.yaml:20)
+            p.requires_grad_(False)
+        self.flat = _flat_padded(denoiser, world)
+        self.opt = DistributedOptimizer(self.flat, optimizer_cfg, world, rank, group, bucket_bytes, self.cfg.gradient_clip_val)
+        self.plans: Dict[tuple, TrainPlan] = {}
+        self.micro = 0
+        self.global_step = 0
+        self._stale = True
+        self._comm = None
+
+    # ---- plans -------------------------------------------------------------------------------------------
+    def plan_for(self, b, v_c, v_t, hl, wl) -> TrainPlan:
+        key = (b, v_c, v_t, hl, wl)
+        tp = self.plans.get(key)
+        if tp is None:
+            acc = self.cfg.accumulate_grad_batches
+            tp = TrainPlan(self.denoiser, self.flat, b, v_c, v_t, hl, wl, self.dtype, loss_scale=1.0 / acc,
+                           grad_scale=1.0 / (acc * self.world), graph=self.graph and self.world == 1)
+            used = {id(p) for p in self.flat.params}
+            missing = used - tp.touched
+            assert not missing, f"{len(missing)} trained parameter(s) never entered the training graph (static exclusion list is incomplete)"
+            self.plans[key] = tp
+            self.flat.zero_grad()
+        return tp
+
+    # ---- the reference's training_step, host part (diffusion_wrapper.py:324-400) ---------------------------
+    def prepare(self, batch, index=None, relative_pose=None, unconditional=None, noise=None, timestep=None, encode_noise=None):
+        """returns (plan, loaded) after staging one micro-batch.  The random choices of the reference (context count
+        :336, relative vs absolute poses :346, CFG drop :381, noise :362, timesteps :363) are drawn here the same way unless
+        given explicitly (tests / reproducible runs)."""
+        from .pipeline import VAE_SCALE, absolute_to_relative_camera
+        ctx, tgt = batch["context"], batch["target"]
+        v_c0 = ctx["image"].shape[1]
+        if index is None:
+            index = int(torch.randint(1, v_c0 + 1, size=(1,)).item())
+        c_img, c_ext, c_int, t_img, t_ext, t_int, rel_index = sample_indices(ctx, tgt, index, random=True)
+        b, v_c = c_img.shape[:2]
+        v_t = t_img.shape[1]
+        ext = torch.cat([c_ext, t_ext], dim=1)
+        if relative_pose is None:
+            relative_pose = bool(np.random.choice([False, True], 1, p=[0.50, 0.50])[0])
+        if not relative_pose:          # diffusion_wrapper.py:347-350: the `== 0` branch converts to relative poses
+            ext = absolute_to_relative_camera(ext.float(), index=rel_index).float()
+        intr = torch.cat([c_int, t_int], dim=1)
+        images = torch.cat([c_img, t_img], dim=1)
+        dev = self.flat.flat.device
+        x = images.reshape(b * (v_c + v_t), *images.shape[2:]).to(dev, torch.float32).contiguous()
+        with torch.no_grad():
+            post = self.autoencoder.encode(x, dtype=self.dtype, pre_scale=2.0, pre_shift=-1.0).latent_dist
+            lat = post.sample(noise=encode_noise, scale=VAE_SCALE)               # [b*v, 4, hl, wl]
+        hl, wl = lat.shape[-2:]
+        lat = lat.view(b, v_c + v_t, -1, hl, wl)
+        if unconditional is None:
+            unconditional = bool(np.random.choice([False, True], 1, p=[0.90, 0.10])[0]) if self.cfg.cfg_train else True
+        if noise is None:
+            noise = torch.randn((b, v_t, lat.shape[2], hl, wl), device=dev)
+        if timestep is None:
+            timestep = torch.randint(0, self.cfg.num_train_timesteps, size=(b,), device=dev, dtype=torch.long)
+        vc_eff = 0 if unconditional else v_c
+        tp = self.plan_for(b, vc_eff, v_t, hl, wl)
+        v = vc_eff + v_t
+        keep = slice(v_c, None) if unconditional else slice(None)
+        tp.latents.copy_(lat[:, keep].reshape(tp.latents.shape))
+        tp.noise.copy_(noise.reshape(tp.noise.shape))
+        na = tp.noise_all.view(b, v, *tp.noise_all.shape[1:])
+        na[:, vc_eff:].copy_(noise.to(dev))
+        ac = self.scheduler.alphas_cumprod.to(dev)
+        t_dev = timestep.to(dev)
+        coef = torch.zeros(b, v, 2, device=dev)
+        coef[:, :vc_eff, 0] = 1.0
+        coef[:, vc_eff:, 0] = (ac[t_dev] ** 0.5)[:, None]
+        coef[:, vc_eff:, 1] = ((1 - ac[t_dev]) ** 0.5)[:, None]
+        tp.coef.copy_(coef.view(b * v, 2))
+        ts = torch.zeros(b, v, dtype=torch.int64, device=dev)
+        ts[:, vc_eff:] = t_dev[:, None]
+        tp.timesteps.copy_(ts.view(-1))
+        tp.extr.copy_(ext[:, keep].reshape(b * v, 4, 4))
+        tp.intr.copy_(intr[:, keep].reshape(b * v, 3, 3))
+        return tp
+
+    def training_step(self, batch, **choices) -> torch.Tensor:
+        """one micro-batch: forward + loss + backward (gradients accumulate in the flat buffer); every
+        `accumulate_grad_batches`-th call also clips, steps AdamW and advances the LR schedule.  Returns the
+        micro-batch's (unscaled) loss as a device scalar."""
+        acc = self.cfg.accumulate_grad_batches
+        if self.micro % acc == 0:
+            self.flat.zero_grad()
+            for tp in self.plans.values():
+                tp.loss.zero_()
+        tp = self.prepare(batch, **choices)
+        if self._stale:
+            for p_ in self.plans.values():
+                p_.refresh_weights()
+            self._stale = False
+        before = tp.loss.clone()
+        last_micro = (self.micro + 1) % acc == 0
+        if self.world > 1 and last_micro:
+            self._run_overlapped(tp)
+        else:
+            tp.run()
+        loss = (tp.loss - before) * acc
+        self.micro += 1
+        if last_micro:
+            self.opt.step()
+            self.global_step += 1
+            self._stale = True
+        return loss.squeeze(0)
+
+    def _run_overlapped(self, tp: TrainPlan):
+        """backward in segments: as soon as the last write into a bucket has been issued, its reduce-scatter starts on
+        RCCL's stream while the remaining (earlier-layer) backward kernels keep the compute stream busy"""
+        n_ops = len(tp.plan)
+        cuts = bucket_cut_points(tp.grad_writes, self.opt.buckets, n_ops)
+        done = 0
+        for k, end in cuts:
+            if end > done:
+                tp.run(done, end)
+                done = end
+            self.opt.reduce_bucket(k)
+        if done < n_ops:
+            tp.run(done, n_ops)
+
+
+def bucket_cut_points(grad_writes: Sequence[Tuple[int, int]], buckets: Sequence[Tuple[int, int]], n_ops: int) -> List[Tuple[int, int]]:
+    """for every bucket, the plan index right after the LAST op that writes a parameter gradient inside it; returned as
+    [(bucket, end index)] sorted by end index (the order the buckets become ready).  A bucket nothing writes to (padding,
+    zero-gradient parameters) is ready at once."""
+    last = {k: 0 for k in range(len(buckets))}
+    for op_idx, off in grad_writes:
+        for k, (a, b) in enumerate(buckets):
+            if a <= off < b:
+                last[k] = max(last[k], op_idx + 1)
+                break
+    return sorted(((k, min(e, n_ops)) for k, e in last.items()), key=lambda t: (t[1], -t[0]))
+
+
+def _flat_padded(denoiser, world: int) -> FlatParams:
+    flat = FlatParams(denoiser, exclude=never_trained(denoiser))
+    q = world * 4
+    if flat.numel % q:       # pad the buffers so that every bucket splits evenly over the ranks
+        pad = q - flat.numel % q
+        dev = flat.flat.device
+        new_p, new_g = torch.zeros(flat.numel + pad, device=dev), torch.zeros(flat.numel + pad, device=dev)
+        new_p[:flat.numel].copy_(flat.flat)
+        flat.flat, flat.grad, flat.numel = new_p, new_g, flat.numel + pad
+        with torch.no_grad():
+            for p in flat.params:
+                o, n = flat.offset[id(p)], p.numel()
+                p.data = flat.flat[o:o + n].view(p.shape)
+                p.grad = flat.grad[o:o + n].view(p.shape)
+    return flat
+
+
+def sample_indices(ctx: dict, tgt: dict, index: int, random: bool = True):
+    """`DiffusionWrapper.sample_indices` (diffusion_wrapper.py:213-276) on the tensors the training path uses:
+    index > 1: the first `index` context views condition, relative index drawn in [0, index); else ONE context view
+    (random or the first) conditions and the others join the targets.  Returns
+    (ctx image, extrinsics, intrinsics, tgt image, extrinsics, intrinsics, rel_index)."""
+    v_c = ctx["image"].shape[1]
+    if index > 1:
+        rel_index = int(torch.randint(0, index, size=(1,), dtype=torch.long).item())
+        return (ctx["image"][:, :index], ctx["extrinsics"][:, :index], ctx["intrinsics"][:, :index],
+                tgt["image"], tgt["extrinsics"], tgt["intrinsics"], rel_index)
+    idx = int(torch.randint(0, v_c, size=(1,), dtype=torch.long).item()) if random else 0
+    mask = torch.zeros(v_c, dtype=torch.bool)
+    mask[idx] = True
+    cat = lambda k: torch.cat([tgt[k], ctx[k][:, ~mask]], dim=1)
+    return (ctx["image"][:, mask], ctx["extrinsics"][:, mask], ctx["intrinsics"][:, mask],
+            cat("image"), cat("extrinsics"), cat("intrinsics"), idx)

@@ -54,6 +54,6 @@ def test_struct_layout_matches_header(tmp_path):
 def test_op_kind_enum_matches():
     from mv_ldm_amd import _lib
     m = re.search(r"enum\s*\{\s*MVLDM_OP_IGEMM = 1(.*?)\};", HEADER, re.S)
-    names = ["MVLDM_OP_IGEMM"] + re.findall(r"(MVLDM_OP_[A-Z_]+)", m.group(1))
+    names = ["MVLDM_OP_IGEMM"] + re.findall(r"(MVLDM_OP_[A-Z0-9_]+)", m.group(1))
     for i, n in enumerate(names, start=1):
         assert getattr(_lib, n.replace("MVLDM_", "")) == i
