@@ -672,10 +672,8 @@ class TrainPlan:
         self.touched, self.grad_writes, self.repack = bld.touched, bld.grad_writes, bld.repack
         self.plan: Plan = bld.finalize(autotune=False)
         self.graph = graph
-        if graph:
+        if graph:       # (capturing runs the plan once eagerly: the caller restores the gradient / loss accumulators)
             self.plan.capture()
-            self.loss.zero_()
-            flat.zero_grad()
 
     def refresh_weights(self):
         for fn in self.repack:
@@ -867,32 +865,37 @@ class MVLDMTrainer:
         tp = self.plans.get(key)
         if tp is None:
             acc = self.cfg.accumulate_grad_batches
+            use_graph = self.graph and self.world == 1
+            saved = self.flat.grad.clone() if use_graph else None       # a plan recorded mid-accumulation must not disturb it
             tp = TrainPlan(self.denoiser, self.flat, b, v_c, v_t, hl, wl, self.dtype, loss_scale=1.0 / acc,
-                           grad_scale=1.0 / (acc * self.world), graph=self.graph and self.world == 1)
+                           grad_scale=1.0 / (acc * self.world), graph=use_graph)
+            if saved is not None:
+                self.flat.grad.copy_(saved)
+                tp.loss.zero_()
             used = {id(p) for p in self.flat.params}
             missing = used - tp.touched
             assert not missing, f"{len(missing)} trained parameter(s) never entered the training graph (static exclusion list is incomplete)"
             self.plans[key] = tp
-            self.flat.zero_grad()
         return tp
 
     # ---- the reference's training_step, host part (diffusion_wrapper.py:324-400) ---------------------------
-    def prepare(self, batch, index=None, relative_pose=None, unconditional=None, noise=None, timestep=None, encode_noise=None):
+    def prepare(self, batch, index=None, second=None, relative_coin=None, unconditional=None, noise=None, timestep=None, encode_noise=None):
         """returns (plan, loaded) after staging one micro-batch.  The random choices of the reference (context count
         :336, relative vs absolute poses :346, CFG drop :381, noise :362, timesteps :363) are drawn here the same way unless
-        given explicitly (tests / reproducible runs)."""
+        given explicitly (tests / reproducible runs): `second` = the second torch.randint of sample_indices (relative index, or
+        which context view is kept), `relative_coin` / `unconditional` = what the two np.random.choice calls returned."""
         from .pipeline import VAE_SCALE, absolute_to_relative_camera
         ctx, tgt = batch["context"], batch["target"]
         v_c0 = ctx["image"].shape[1]
         if index is None:
             index = int(torch.randint(1, v_c0 + 1, size=(1,)).item())
-        c_img, c_ext, c_int, t_img, t_ext, t_int, rel_index = sample_indices(ctx, tgt, index, random=True)
+        c_img, c_ext, c_int, t_img, t_ext, t_int, rel_index = sample_indices(ctx, tgt, index, random=True, second=second)
         b, v_c = c_img.shape[:2]
         v_t = t_img.shape[1]
         ext = torch.cat([c_ext, t_ext], dim=1)
-        if relative_pose is None:
-            relative_pose = bool(np.random.choice([False, True], 1, p=[0.50, 0.50])[0])
-        if not relative_pose:          # diffusion_wrapper.py:347-350: the `== 0` branch converts to relative poses
+        if relative_coin is None:
+            relative_coin = bool(np.random.choice([False, True], 1, p=[0.50, 0.50])[0])
+        if not relative_coin:          # diffusion_wrapper.py:347-350: `if relative_pose == 0` converts to RELATIVE poses
             ext = absolute_to_relative_camera(ext.float(), index=rel_index).float()
         intr = torch.cat([c_int, t_int], dim=1)
         images = torch.cat([c_img, t_img], dim=1)
@@ -1004,17 +1007,17 @@ def _flat_padded(denoiser, world: int) -> FlatParams:
     return flat
 
 
-def sample_indices(ctx: dict, tgt: dict, index: int, random: bool = True):
+def sample_indices(ctx: dict, tgt: dict, index: int, random: bool = True, second: Optional[int] = None):
     """`DiffusionWrapper.sample_indices` (diffusion_wrapper.py:213-276) on the tensors the training path uses:
     index > 1: the first `index` context views condition, relative index drawn in [0, index); else ONE context view
     (random or the first) conditions and the others join the targets.  Returns
     (ctx image, extrinsics, intrinsics, tgt image, extrinsics, intrinsics, rel_index)."""
     v_c = ctx["image"].shape[1]
     if index > 1:
-        rel_index = int(torch.randint(0, index, size=(1,), dtype=torch.long).item())
+        rel_index = int(torch.randint(0, index, size=(1,), dtype=torch.long).item()) if second is None else int(second)
         return (ctx["image"][:, :index], ctx["extrinsics"][:, :index], ctx["intrinsics"][:, :index],
                 tgt["image"], tgt["extrinsics"], tgt["intrinsics"], rel_index)
-    idx = int(torch.randint(0, v_c, size=(1,), dtype=torch.long).item()) if random else 0
+    idx = (int(torch.randint(0, v_c, size=(1,), dtype=torch.long).item()) if random else 0) if second is None else int(second)
     mask = torch.zeros(v_c, dtype=torch.bool)
     mask[idx] = True
     cat = lambda k: torch.cat([tgt[k], ctx[k][:, ~mask]], dim=1)

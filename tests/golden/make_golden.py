@@ -277,8 +277,102 @@ def g6():
     save("g6_ddim", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G9
+G9_FULL = ("unet.conv_in.weight", "unet.conv_out.weight", "unet.conv_out.bias", "unet.time_embedding.linear_1.weight",
+           "unet.down_blocks.0.resnets.0.time_emb_proj.weight", "unet.down_blocks.0.resnets.0.norm1.weight",
+           "unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+           "unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.bias",
+           "unet.down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_out.0.bias",
+           "unet.down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.bias",
+           "unet.down_blocks.1.downsamplers.0.conv.weight", "unet.mid_block.resnets.1.conv2.bias",
+           "unet.up_blocks.2.resnets.0.conv_shortcut.weight", "unet.up_blocks.1.upsamplers.0.conv.weight",
+           "unet.up_blocks.3.resnets.2.norm1.bias", "cross_attn_blocks_encoder.0.transformer_blocks.0.attn1.to_k.weight",
+           "cross_attn_blocks_mid.0.transformer_blocks.0.norm2.weight", "cross_attn_blocks_decoder.3.proj_out.weight",
+           "cross_attn_blocks_decoder.2.transformer_blocks.0.ff.net.2.weight")
+
+
+def g9():
+    """`DiffusionWrapper.training_step` of the REFERENCE (diffusion_wrapper.py:324-411) + autograd, with its random draws
+    (context count :336, view choice :225/:235, relative-pose coin :346, noise :362, timesteps :363, CFG coin :381, the VAE
+    posterior noise) replaced by recorded values.  Stored: the inputs, the draws, the loss, the L2 norm of EVERY parameter
+    gradient and a handful of gradients in full."""
+    import numpy as onp
+    out = {}
+    # (b, index draw, second randint draw, relative_pose coin, unconditional coin)
+    cases = [(2, 2, 1, False, False), (1, 1, 1, True, False), (2, 2, 0, False, True)]
+    for ci, (b, index, second, rel_coin, unc_coin) in enumerate(cases):
+        w = _ref_wrapper(True)
+        w.train()
+        w.train_cfg = SimpleNamespace(cfg_train=True, step_offset=0)
+        cs_d = load_seeded(w.denoiser, 500)
+        cs_v = load_seeded(w.autoencoder, 501)
+        H = 32
+        g = torch.Generator().manual_seed(90 + ci)
+        img = torch.rand(b, 5, 3, H, H, generator=g)
+        extr, intr = random_cameras(b, 5, seed=95 + ci)
+        extr = extr.roll(1, dims=1)                     # no identity pose at view 0
+        view = lambda sl: {"image": img[:, sl].clone(), "extrinsics": extr[:, sl].clone(), "intrinsics": intr[:, sl].clone(),
+                           "near": torch.ones(b, img[:, sl].shape[1]), "far": torch.full((b, img[:, sl].shape[1]), 100.0),
+                           "index": torch.arange(5)[sl][None].expand(b, -1).clone()}
+        batch = {"context": view(slice(0, 2)), "target": view(slice(2, 5)), "scene": ["synthetic"] * b}
+        hl = H // 2
+        v_c = index if index > 1 else 1
+        v_t = 5 - v_c
+        enc_noise = torch.randn(b * 5, 4, hl, hl, generator=g)
+        noise = torch.randn(b, v_t, 4, hl, hl, generator=g)
+        tsteps = torch.randint(0, 1000, (b,), generator=g)
+        ints = [torch.tensor([index]), torch.tensor([second]), tsteps]
+        coins = [onp.array([rel_coin]), onp.array([unc_coin])]
+        o_randint, o_randn, o_randn_like, o_choice = torch.randint, torch.randn, torch.randn_like, onp.random.choice
+
+        def fake_randint(*a, **k):
+            return ints.pop(0).clone()
+
+        def fake_randn(*shape, **k):
+            shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            assert shp == tuple(enc_noise.shape), shp
+            return enc_noise.clone()
+
+        def fake_randn_like(t, **k):
+            assert tuple(t.shape) == tuple(noise.shape)
+            return noise.clone()
+        torch.randint, torch.randn, torch.randn_like, onp.random.choice = fake_randint, fake_randn, fake_randn_like, lambda *a, **k: coins.pop(0)
+        try:
+            with R.cpu_cuda(), torch.enable_grad():
+                for prm in w.denoiser.parameters():
+                    prm.requires_grad_(True)
+                loss = w.training_step(batch, 0)
+        finally:
+            torch.randint, torch.randn, torch.randn_like, onp.random.choice = o_randint, o_randn, o_randn_like, o_choice
+        assert not ints and not coins
+        w.denoiser.zero_grad()
+        with torch.enable_grad():
+            loss.backward()
+        p = f"c{ci}_"
+        names, norms = [], []
+        for n_, prm in w.denoiser.named_parameters():
+            names.append(n_)
+            norms.append(-1.0 if prm.grad is None else float(prm.grad.double().norm()))
+        out.update({p + "b": b, p + "index": index, p + "second": second, p + "relative_coin": int(rel_coin), p + "unconditional": int(unc_coin),
+                    p + "image": img, p + "extr": extr, p + "intr": intr, p + "enc_noise": enc_noise, p + "noise": noise, p + "timesteps": tsteps,
+                    p + "loss": float(loss), p + "grad_norms": onp.array(norms), p + "checksum_denoiser": cs_d, p + "checksum_vae": cs_v})
+        sd = dict(w.denoiser.named_parameters())
+        for k_ in G9_FULL:       # up to 2048 evenly strided entries of the flattened gradient (the norms above cover the rest)
+            gflat = sd[k_].grad.detach().reshape(-1)
+            out[p + "grad/" + k_] = gflat[::max(1, gflat.numel() // 2048)][:2048].clone()
+        unused = [n_ for n_, v_ in zip(names, norms) if v_ < 0]
+        zero = [n_ for n_, v_ in zip(names, norms) if v_ == 0]
+        print(f"  g9 case {ci}: b={b} index={index} uncond={unc_coin}: loss {float(loss):.6f}; {len(unused)} params without grad, {len(zero)} with zero grad")
+        if ci == 0:
+            out["names"] = onp.array(names)
+    out["n"] = len(cases)
+    out["widths"] = np.array([64, 128, 256, 256])
+    out["vae_widths"] = np.array([32, 64])
+    save("g9_training_step", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g9"]
     if "g1" in which:
         g1_g2()
     if "g3" in which:
@@ -289,6 +383,8 @@ if __name__ == "__main__":
         g5()
     if "g6" in which:
         g6()
+    if "g9" in which:
+        g9()
     if "g7" in which:
         from make_golden_schedules import g7
         g7()
