@@ -126,6 +126,66 @@ def pmc_traffic(args, b):
     return None if ent is None else round(ent["families"]["igemm"]["hbm_bytes_per_launch"])
 
 
+def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params):
+    """BASELINE.json configs[3]: one "step" = one optimizer step = `accumulate_grad_batches` (2) micro-batches of B scenes x
+    (1 ctx + 3 tgt) views at 256x256 per GPU -- VAE encode of all views, add_noise, UNet forward, MSE, backward, then clip
+    0.1 + AdamW.  N > 1: gradients reduce-scattered bucket by bucket under the backward pass, AdamW on the owned slices,
+    weights all-gathered (ZeRO-1 over RCCL)."""
+    from mv_ldm_amd.dist import max_over_ranks
+    from mv_ldm_amd.scheduler import DDIMScheduler
+    from mv_ldm_amd.train import MVLDMTrainer
+    torch.set_grad_enabled(False)
+    b = args.scenes if args.scenes != 64 else 4
+    tr = MVLDMTrainer(den, vae, DDIMScheduler(clip_sample=False), dtype=dtype, world=world, rank=rank)
+    g = torch.Generator().manual_seed(77 + rank)
+    batch = synthetic_batch(b, 1, 3, args.res, 4000 + rank, dev)
+    batch["target"]["image"] = torch.rand(b, 3, 3, args.res, args.res, generator=g).to(dev)
+    acc = tr.cfg.accumulate_grad_batches
+    losses = []
+    for _ in range(args.warmup * acc):
+        tr.training_step(batch, index=1, unconditional=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * acc):
+        losses.append(tr.training_step(batch, index=1, unconditional=False))
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev if backend == "nccl" else None)
+    views = world * b * 4 * acc * args.steps
+    out = {"metric": "training views/sec (fwd + bwd + optimizer) @ 256x256, 4 views/scene", "value": round(views / elapsed, 3), "unit": "views/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+           "data": "synthetic RE10K-shaped scenes; random-init weights",
+           "config": {"workload": f"configs[3]: optimizer step = {acc} micro-batches of {b} scenes x (1 ctx + 3 tgt) @ {args.res}x{args.res} per GPU: VAE "
+                                  "encode, add_noise, UNet fwd+bwd (SD-2.1 topology + 9 multi-view blocks), MSE, clip 0.1, AdamW (fp32 master weights)",
+                      "scenes_per_gpu": b, "params": n_params, "trained_params": int(tr.flat.numel),
+                      "parallelism": f"data parallel x{world}: ZeRO-1 reduce-scatter + all-gather" if world > 1 else "single GPU"},
+           "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)], "grad_norm": round(float(tr.opt.norm[0]), 4)}
+    if rank == 0 and not args.no_profile:
+        tp = next(iter(tr.plans.values()))
+        tp.plan.profile(1)
+        ms = tp.plan.profile(2)
+        tr.flat.zero_grad()
+        agg = {}
+        for m, t in zip(tp.plan.meta, ms):
+            part = "backward" if m.name.startswith("backward") else ("inputs" if m.name.startswith("inputs") else "forward+loss")
+            a = agg.setdefault(part, [0.0, 0.0])
+            a[0] += t; a[1] += m.flops
+        out["micro_batch_ms"] = {k: round(v[0], 3) for k, v in agg.items()}
+        out["micro_batch_tflops"] = {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) for k, v in agg.items() if v[1] > 0}
+        fl = sum(m.flops for m in tp.plan.meta)
+        out["roofline"] = {"bound": "mfma", "kernel": "training micro-batch plan (igemm fwd / dgrad / wgrad + attention fwd / bwd)",
+                           "achieved": round(fl / (sum(ms) * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                           "frac": round(fl / (sum(ms) * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4), "traffic": None}
+        if args.op_table:
+            with open(args.op_table, "w") as f:
+                json.dump([{"name": m.name, "kind": m.kind, "ms": t, "flops": m.flops, "bytes": m.bytes} for m, t in zip(tp.plan.meta, ms)], f, indent=0)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +200,9 @@ def main():
     ap.add_argument("--op-table", default=None, help="write the per-op profile (JSON) here")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the b in {1, 4, 16} latency lines")
     ap.add_argument("--no-parity", action="store_true", help="skip the 50-step f32-vs-bench-dtype drift measurement")
+    ap.add_argument("--train", action="store_true",
+                    help="measure the TRAINING step instead (BASELINE.json configs[3]): K optimizer steps of 2 micro-batches of "
+                         "--scenes x 4 views, bf16, AdamW, clip 0.1; N > 1: ZeRO-1 reduce-scatter / all-gather over RCCL")
     ap.add_argument("--unet-pass-only", action="store_true",
                     help="run ONE eager UNet+DDIM pass and exit (the population `roofline` is quoted on; used for PMC passes)")
     args = ap.parse_args()
@@ -183,6 +246,15 @@ def main():
     random_init_(den, 1234)
     random_init_(vae, 1235)
     n_params = sum(p.numel() for p in den.parameters())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.train:
+        return train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params)
     pipe = MVLDMPipeline(den, vae, DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, args.ddim_steps))
     pipe.set_timesteps(args.ddim_steps)
     b, v_c, v_t = args.scenes, 1, 4
@@ -190,12 +262,6 @@ def main():
     from mv_ldm_amd.dist import gather_counts, shard_scenes
     owned = shard_scenes(world * b, rank, world)
     batch = synthetic_batch(b, v_c, v_t, args.res, 1234, dev, scene_ids=owned)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     if args.unet_pass_only:
         st = pipe.prepare(batch)

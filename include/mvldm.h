@@ -32,9 +32,10 @@ enum { MVLDM_F32 = 0, MVLDM_BF16 = 1, MVLDM_F16 = 2 };
 enum { MVLDM_OK = 0, MVLDM_ERR_ARG = -1, MVLDM_ERR_HIP = -2, MVLDM_ERR_UNSUPPORTED = -3 };
 
 /* epilogue selector of the implicit GEMM */
-enum { MVLDM_EPI_NONE = 0, MVLDM_EPI_SILU = 1, MVLDM_EPI_GEGLU = 2 };
+enum { MVLDM_EPI_NONE = 0, MVLDM_EPI_SILU = 1, MVLDM_EPI_GEGLU = 2, MVLDM_EPI_GELU = 3 /* exact (erf) GELU: the ViT feed-forward of the
+       "standard" multi-view block, src/model/transformer/feed_forward.py:31-40 */ };
 /* elementwise op selector */
-enum { MVLDM_ELT_COPY = 0, MVLDM_ELT_SILU = 1 };
+enum { MVLDM_ELT_COPY = 0, MVLDM_ELT_SILU = 1, MVLDM_ELT_GELU = 2 };
 
 int mvldm_abi_version(void);
 const char* mvldm_last_error(void);
@@ -197,12 +198,21 @@ int mvldm_nhwc_to_nchw(const void* src, float* dst, int n_img, int c, int hw, in
  * sample_image_grid, unproject, get_world_rays).  extrinsics: fp32 [n_cam][4][4] camera-to-world;
  * intrinsics: fp32 [n_cam][3][3] normalised.  Per latent pixel (i, j): xy = ((j+.5)/w, (i+.5)/h),
  * d = normalize(K^-1 [x y 1]), direction = R d, origin = translation.  Outputs (either may be NULL):
- * out_nchw fp32 [n_cam][6][h*w]; out_nhwc: channels [nhwc_c_off, +6) of an NHWC buffer [..][h*w][nhwc_c]
+ * out_nchw fp32 [n_cam][C][h*w]; out_nhwc: channels [nhwc_c_off, +C) of an NHWC buffer [..][h*w][nhwc_c]
  * in nhwc_dtype, camera i -> image img_map[i] (NULL: i).
+ * Encodings of the (origin, direction) pair (diffusion_wrapper.py:98-127,301-322):
+ *   MVLDM_RAYS_RAW        [o | d]: 6 channels (the released config: use_ray_encoding = srt_ray_encoding = false)
+ *   MVLDM_RAYS_POSITIONAL src/model/encodings/positional_encoding.py:8-36 on o (n_origin_octaves) then d (n_dir_octaves):
+ *                         per coordinate, per octave f: sin(x * 2 pi 2^f), sin(x * 2 pi 2^f + pi/2); 6 * octaves channels each
+ *                         (0 octaves: that part is passed through raw, `nn.Identity`)
+ *   MVLDM_RAYS_SRT        src/model/srt/layers.py:11-58 (RayEncoder): [sin(o 2^f pi) | cos(o 2^f pi) | sin(d 2^f pi) | cos(...)]
+ * plucker != 0: o is replaced by o x d first (diffusion_wrapper.py:309-310).  The channel count is mvldm_ray_channels().
  */
+enum { MVLDM_RAYS_RAW = 0, MVLDM_RAYS_POSITIONAL = 1, MVLDM_RAYS_SRT = 2 };
+int mvldm_ray_channels(int mode, int n_origin_octaves, int n_dir_octaves);
 int mvldm_ray_encode(const float* extrinsics, const float* intrinsics, int n_cam, int h, int w, float* out_nchw,
-                     void* out_nhwc, int nhwc_c, int nhwc_c_off, int nhwc_dtype, const int32_t* img_map,
-                     mvldm_stream_t stream);
+                     void* out_nhwc, int nhwc_c, int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, int mode,
+                     int n_origin_octaves, int n_dir_octaves, int plucker, mvldm_stream_t stream);
 
 /* AutoencoderKL.encode(x).latent_dist.sample() * scale (diffusion_wrapper.py:283; diffusers
  * DiagonalGaussianDistribution): moments fp32 NCHW [n][2c][hw] = [mean | logvar], noise / out fp32 [n][c][hw];
@@ -276,8 +286,9 @@ int mvldm_attention_bwd(const mvldm_attn_bwd_desc* d, mvldm_stream_t stream);
  *   MVLDM_TE_SILU_BWD   out = b * silu'(a)                      (a: pre-activation, dtype a_dtype; b: upstream gradient)
  *   MVLDM_TE_ADD        out += a                                 (gradient accumulation; b unused)
  *   MVLDM_TE_GEGLU_FWD  out[rows][d] = a[:, :d] * gelu(a[:, d:])            (a: [rows][2d]; diffusers GEGLU / mvdream attention.py:60-73)
- *   MVLDM_TE_GEGLU_BWD  out[rows][2d] = d/da of the above times b[rows][d] */
-enum { MVLDM_TE_SILU_BWD = 0, MVLDM_TE_ADD = 1, MVLDM_TE_GEGLU_FWD = 2, MVLDM_TE_GEGLU_BWD = 3 };
+ *   MVLDM_TE_GEGLU_BWD  out[rows][2d] = d/da of the above times b[rows][d]
+ *   MVLDM_TE_GELU_BWD   out = b * gelu'(a)                      (a: pre-activation) */
+enum { MVLDM_TE_SILU_BWD = 0, MVLDM_TE_ADD = 1, MVLDM_TE_GEGLU_FWD = 2, MVLDM_TE_GEGLU_BWD = 3, MVLDM_TE_GELU_BWD = 4 };
 int mvldm_train_eltwise(int op, const void* a, const void* b, void* out, size_t rows, int d, int a_dtype, int dtype,
                         mvldm_stream_t stream);
 /* backward of nearest-2x upsampling: dx[n][i][j][c] = sum of the 2x2 block of du [n][2h][2w][c] */
@@ -345,7 +356,7 @@ typedef struct mvldm_op {
         struct { const void* src; void* dst; int32_t n_img, c, hw, other_c, other_c_off, dtype, clamp01;
                  float scale, shift; const int32_t* img_map; } layout;
         struct { const float* extrinsics; const float* intrinsics; float* out_nchw; void* out_nhwc; const int32_t* img_map;
-                 int32_t n_cam, h, w, nhwc_c, nhwc_c_off, nhwc_dtype; } rays;
+                 int32_t n_cam, h, w, nhwc_c, nhwc_c_off, nhwc_dtype, mode, n_origin_octaves, n_dir_octaves, plucker; } rays;
         struct { const float* moments; const float* noise; float* out; int32_t n, c, hw; float scale; } posterior;
         mvldm_wgrad_desc wgrad;
         mvldm_attn_bwd_desc attention_bwd;

@@ -19,6 +19,7 @@ def __getattr__(name):
         "UNet2DConditionModel": "modules", "Transformer2DModel": "modules", "ResnetBlock2D": "modules",
         "MultiViewUNet": "mvunet", "MultiViewUNetCfg": "mvunet", "UNet2DModelCfg": "mvunet",
         "SpatialTransformer3D": "mvunet", "SpatialTransformer3DCfg": "mvunet", "get_attn_blocks": "mvunet",
+        "StandardTransformer": "mvunet", "CrossAttentionCfg": "mvunet", "RayEncodingCfg": "pipeline",
         "DENOISER": "mvunet", "get_denoiser": "mvunet",
         "DDIMScheduler": "scheduler", "DDIMSchedulerCfg": "scheduler", "SchedulerCfg": "scheduler",
         "SCHEDULER": "scheduler", "get_scheduler": "scheduler",

@@ -13,15 +13,16 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmvldm_hip.so"
 
 ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
-EPI_NONE, EPI_SILU, EPI_GEGLU = 0, 1, 2
-ELT_COPY, ELT_SILU = 0, 1
+EPI_NONE, EPI_SILU, EPI_GEGLU, EPI_GELU = 0, 1, 2, 3
+RAYS_RAW, RAYS_POSITIONAL, RAYS_SRT = 0, 1, 2
+ELT_COPY, ELT_SILU, ELT_GELU = 0, 1, 2
 GN_MAX_CHUNKS = 32
 
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_TIMESTEP_EMBED, OP_ELTWISE, OP_DDIM_STEP, OP_DDIM_ADVANCE,
  OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY, OP_RAY_ENCODE, OP_POSTERIOR_SAMPLE,
  OP_WGRAD, OP_ATTENTION_BWD, OP_GROUPNORM_BWD, OP_LAYERNORM_BWD, OP_COLSUM, OP_TRAIN_ELTWISE, OP_POOL2X2, OP_ZERO_INSERT,
  OP_ADD_NOISE, OP_MSE_LOSS, OP_FILL_ZERO) = range(1, 25)
-TE_SILU_BWD, TE_ADD, TE_GEGLU_FWD, TE_GEGLU_BWD = 0, 1, 2, 3
+TE_SILU_BWD, TE_ADD, TE_GEGLU_FWD, TE_GEGLU_BWD, TE_GELU_BWD = 0, 1, 2, 3, 4
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 
@@ -79,7 +80,8 @@ class _Layout(C.Structure):
 
 class _Rays(C.Structure):
     _fields_ = [("extrinsics", vp), ("intrinsics", vp), ("out_nchw", vp), ("out_nhwc", vp), ("img_map", vp),
-                ("n_cam", i32), ("h", i32), ("w", i32), ("nhwc_c", i32), ("nhwc_c_off", i32), ("nhwc_dtype", i32)]
+                ("n_cam", i32), ("h", i32), ("w", i32), ("nhwc_c", i32), ("nhwc_c_off", i32), ("nhwc_dtype", i32),
+                ("mode", i32), ("n_origin_octaves", i32), ("n_dir_octaves", i32), ("plucker", i32)]
 
 
 class _Posterior(C.Structure):
@@ -187,7 +189,8 @@ SIGNATURES = {
     "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
     "mvldm_ddim_advance": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, vp, vp]),
-    "mvldm_ray_encode": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "mvldm_ray_channels": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mvldm_ray_encode": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp] + [C.c_int] * 4 + [vp]),
     "mvldm_posterior_sample": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
     "mvldm_nhwc_to_nchw": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, C.c_int, vp]),
     "mvldm_op_run": (C.c_int, [C.POINTER(Op), vp]),

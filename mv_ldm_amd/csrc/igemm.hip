@@ -175,6 +175,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     float v = acc[i][j][r] + bv;
                     if (p.row_bias) v += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + n];
                     if (p.epilogue == MVLDM_EPI_SILU) v = silu_f(v);
+                    else if (p.epilogue == MVLDM_EPI_GELU) v = gelu_erf_fast(v);
                     epilogue_store<T>(p, m, n, v);
                 }
             }
@@ -195,7 +196,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
 // A wave tile wider than 4 column blocks is parked in groups of <= 4 blocks (the 8 park buffers must fit the ring).
 constexpr int park_blocks(int tn) { return tn <= 4 ? tn : 4; }
 
-enum { EPI_PLAIN = 0, EPI_ACT_SILU = 1, EPI_PAIR_GEGLU = 2, EPI_PARTIAL = 3 };
+enum { EPI_PLAIN = 0, EPI_ACT_SILU = 1, EPI_PAIR_GEGLU = 2, EPI_PARTIAL = 3, EPI_ACT_GELU = 4 };
 
 // one parked group: JN column blocks of one 32-row block.  m0: global row of block row 0; pcol0: first packed
 // column of the group.
@@ -273,6 +274,10 @@ __device__ __forceinline__ void epi_rows(const IgemmParams& p, const float* st, 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
                 }
+                if constexpr (MODE == EPI_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
@@ -311,6 +316,7 @@ __device__ __forceinline__ void epi_group(const IgemmParams& p, const f32x16 (&a
     else if (mode == EPI_PAIR_GEGLU) {
         if constexpr (JN % 2 == 0) epi_rows<T, JN, EPI_PAIR_GEGLU, PITCH>(p, st, m0, pcol0, split, lane);
     } else if (mode == EPI_ACT_SILU) epi_rows<T, JN, EPI_ACT_SILU, PITCH>(p, st, m0, pcol0, split, lane);
+    else if (mode == EPI_ACT_GELU) epi_rows<T, JN, EPI_ACT_GELU, PITCH>(p, st, m0, pcol0, split, lane);
     else epi_rows<T, JN, EPI_PLAIN, PITCH>(p, st, m0, pcol0, split, lane);
 }
 
@@ -325,7 +331,8 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x
     if (p.fake & 8) return;
     float* st = reinterpret_cast<float*>(smem) + wave * (32 * PITCH);
     const int mode = p.splitk > 1 ? EPI_PARTIAL
-                                  : (p.epilogue == MVLDM_EPI_GEGLU ? EPI_PAIR_GEGLU : (p.epilogue == MVLDM_EPI_SILU ? EPI_ACT_SILU : EPI_PLAIN));
+                                  : (p.epilogue == MVLDM_EPI_GEGLU ? EPI_PAIR_GEGLU
+                                     : (p.epilogue == MVLDM_EPI_SILU ? EPI_ACT_SILU : (p.epilogue == MVLDM_EPI_GELU ? EPI_ACT_GELU : EPI_PLAIN)));
     __syncthreads();   // every wave is done with the operand ring
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -961,6 +968,7 @@ template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce
             if (p.bias) a += p.bias[col];
             if (p.row_bias) a += p.row_bias[(size_t)(m / p.hw_out) * p.row_bias_ld + col];
             if (p.epilogue == MVLDM_EPI_SILU) a = silu_f(a);
+            else if (p.epilogue == MVLDM_EPI_GELU) a = gelu_erf_fast(a);
             v = a;
         }
         epilogue_store<T>(p, m, col, v);

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const TS* __restrict__ x, 
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float v = to_f32<TS>(x[i]);
         if (op == MVLDM_ELT_SILU) v = silu_f(v);
+        else if (op == MVLDM_ELT_GELU) v = gelu_erf_f(v);
         y[i] = from_f32<TD>(v);
     }
 }
@@ -113,10 +114,17 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
 // One thread per (camera, pixel); K^-1 by the adjugate (fp32).  Output channels: origin xyz, direction xyz.
 // Either / both of: fp32 NCHW [n_cam][6][hw] (the reference's `ray_encodings` tensor) and a slice
 // [c_off, c_off+6) of an NHWC activation buffer (the UNet input), image i -> row block img_map[i].
+__host__ __device__ inline int ray_channels(int mode, int no, int nd) {
+    if (mode == MVLDM_RAYS_POSITIONAL) return (no > 0 ? 6 * no : 3) + (nd > 0 ? 6 * nd : 3);
+    if (mode == MVLDM_RAYS_SRT) return 6 * no + 6 * nd;
+    return 6;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ray_kernel(const float* __restrict__ extr, const float* __restrict__ intr, int n_cam,
                                                   int h, int w, float* __restrict__ out_nchw, T* __restrict__ out_nhwc,
-                                                  int nhwc_c, int nhwc_c_off, const int32_t* __restrict__ img_map) {
+                                                  int nhwc_c, int nhwc_c_off, const int32_t* __restrict__ img_map, int mode,
+                                                  int no, int nd, int plucker) {
     const int hw = h * w;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_cam * hw) return;
@@ -142,15 +150,49 @@ __global__ __launch_bounds__(256) void ray_kernel(const float* __restrict__ extr
     v[3] = E[0] * dx + E[1] * dy + E[2] * dz;
     v[4] = E[4] * dx + E[5] * dy + E[6] * dz;
     v[5] = E[8] * dx + E[9] * dy + E[10] * dz;
-    if (out_nchw) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) out_nchw[((size_t)cam * 6 + q) * hw + pix] = v[q];
+    if (plucker) {      // origins = cross(origins, directions)   (diffusion_wrapper.py:309-310)
+        const float ox = v[1] * v[5] - v[2] * v[4], oy = v[2] * v[3] - v[0] * v[5], oz = v[0] * v[4] - v[1] * v[3];
+        v[0] = ox; v[1] = oy; v[2] = oz;
     }
-    if (out_nhwc) {
-        const int dimg = img_map ? img_map[cam] : cam;
-        T* o = out_nhwc + ((size_t)dimg * hw + pix) * nhwc_c + nhwc_c_off;
+    const int nch = ray_channels(mode, no, nd);
+    const int dimg = img_map ? img_map[cam] : cam;
+    T* onh = out_nhwc ? out_nhwc + ((size_t)dimg * hw + pix) * nhwc_c + nhwc_c_off : nullptr;
+    auto put = [&](int ch, float val) {
+        if (out_nchw) out_nchw[((size_t)cam * nch + ch) * hw + pix] = val;
+        if (onh) onh[ch] = from_f32<T>(val);
+    };
+    if (mode == MVLDM_RAYS_RAW) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) o[q] = from_f32<T>(v[q]);
+        for (int q = 0; q < 6; ++q) put(q, v[q]);
+    } else if (mode == MVLDM_RAYS_POSITIONAL) {
+        // positional_encoding.py:30-33: sin(x * (2 pi 2^f) + phase), phase in {0, pi/2}; channel order (coordinate, octave, phase)
+        int ch = 0;
+        for (int part = 0; part < 2; ++part) {
+            const int oct = part == 0 ? no : nd;
+            for (int q = 0; q < 3; ++q) {
+                const float val = v[part * 3 + q];
+                if (oct == 0) { put(ch++, val); continue; }
+                for (int fo = 0; fo < oct; ++fo) {
+                    const float fr = __fmul_rn(6.283185307179586f, exp2f((float)fo));       // 2 * torch.pi * 2**octave in fp32
+                    const float arg = __fmul_rn(val, fr);
+                    put(ch++, sinf(arg));
+                    put(ch++, sinf(__fadd_rn(arg, 1.5707963267948966f)));
+                }
+            }
+        }
+    } else {
+        // srt/layers.py:17-33: multipliers 2^f pi; [sines (coordinate, octave) | cosines (coordinate, octave)] for o, then for d
+        int base = 0;
+        for (int part = 0; part < 2; ++part) {
+            const int oct = part == 0 ? no : nd;
+            for (int q = 0; q < 3; ++q)
+                for (int fo = 0; fo < oct; ++fo) {
+                    const float arg = __fmul_rn(v[part * 3 + q], __fmul_rn(exp2f((float)fo), 3.141592653589793f));
+                    put(base + q * oct + fo, sinf(arg));
+                    put(base + 3 * oct + q * oct + fo, cosf(arg));
+                }
+            base += 6 * oct;
+        }
     }
 }
 
@@ -173,15 +215,17 @@ __global__ __launch_bounds__(256) void posterior_sample_kernel(const float* __re
 static inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
 
 int ray_run(const float* extr, const float* intr, int n_cam, int h, int w, float* out_nchw, void* out_nhwc, int nhwc_c,
-            int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, hipStream_t s) {
+            int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, int mode, int no, int nd, int plucker, hipStream_t s) {
     MVLDM_REQUIRE(extr && intr && (out_nchw || out_nhwc), "ray_encode: null pointer");
-    MVLDM_REQUIRE(!out_nhwc || nhwc_c_off + 6 <= nhwc_c, "ray_encode: channel slice [%d, %d) outside %d", nhwc_c_off, nhwc_c_off + 6, nhwc_c);
+    MVLDM_REQUIRE(mode >= MVLDM_RAYS_RAW && mode <= MVLDM_RAYS_SRT && no >= 0 && nd >= 0 && no <= 32 && nd <= 32, "ray_encode: mode %d octaves (%d, %d)", mode, no, nd);
+    const int nch = ray_channels(mode, no, nd);
+    MVLDM_REQUIRE(!out_nhwc || nhwc_c_off + nch <= nhwc_c, "ray_encode: channel slice [%d, %d) outside %d", nhwc_c_off, nhwc_c_off + nch, nhwc_c);
     const size_t total = (size_t)n_cam * h * w;
     if (total == 0) return MVLDM_OK;
     return dispatch_dtype(out_nhwc ? nhwc_dtype : MVLDM_F32, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL(ray_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, extr, intr, n_cam, h, w, out_nchw,
-                           reinterpret_cast<T*>(out_nhwc), nhwc_c, nhwc_c_off, img_map);
+                           reinterpret_cast<T*>(out_nhwc), nhwc_c, nhwc_c_off, img_map, mode, no, nd, plucker);
         return check_launch();
     });
 }
@@ -289,10 +333,12 @@ extern "C" int mvldm_nchw_to_nhwc(const float* src, void* dst, int n_img, int c,
                                   int dst_dtype, float scale, float shift, const int32_t* img_map, mvldm_stream_t stream) {
     return to_nhwc_run(src, dst, n_img, c, hw, dst_c, dst_c_off, dst_dtype, scale, shift, img_map, (hipStream_t)stream);
 }
+extern "C" int mvldm_ray_channels(int mode, int n_origin_octaves, int n_dir_octaves) { return ray_channels(mode, n_origin_octaves, n_dir_octaves); }
 extern "C" int mvldm_ray_encode(const float* extrinsics, const float* intrinsics, int n_cam, int h, int w, float* out_nchw,
-                                void* out_nhwc, int nhwc_c, int nhwc_c_off, int nhwc_dtype, const int32_t* img_map,
-                                mvldm_stream_t stream) {
-    return ray_run(extrinsics, intrinsics, n_cam, h, w, out_nchw, out_nhwc, nhwc_c, nhwc_c_off, nhwc_dtype, img_map, (hipStream_t)stream);
+                                void* out_nhwc, int nhwc_c, int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, int mode,
+                                int n_origin_octaves, int n_dir_octaves, int plucker, mvldm_stream_t stream) {
+    return ray_run(extrinsics, intrinsics, n_cam, h, w, out_nchw, out_nhwc, nhwc_c, nhwc_c_off, nhwc_dtype, img_map, mode, n_origin_octaves,
+                   n_dir_octaves, plucker, (hipStream_t)stream);
 }
 extern "C" int mvldm_posterior_sample(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale,
                                       mvldm_stream_t stream) {

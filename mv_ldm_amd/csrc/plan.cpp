@@ -23,7 +23,7 @@ int advance_run(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t*
 int to_nhwc_run(const float* src, void* dst, int n_img, int c, int hw, int dst_c, int dst_c_off, int dst_dtype, float scale,
                 float shift, const int32_t* img_map, hipStream_t s);
 int ray_run(const float* extr, const float* intr, int n_cam, int h, int w, float* out_nchw, void* out_nhwc, int nhwc_c,
-            int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, hipStream_t s);
+            int nhwc_c_off, int nhwc_dtype, const int32_t* img_map, int mode, int no, int nd, int plucker, hipStream_t s);
 int posterior_run(const float* moments, const float* noise, float* out, int n, int c, int hw, float scale, hipStream_t s);
 int wgrad_run(const mvldm_wgrad_desc& d, hipStream_t s);
 int attention_bwd_run(const mvldm_attn_bwd_desc& a, hipStream_t s);
@@ -91,7 +91,7 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         case MVLDM_OP_RAY_ENCODE: {
             const auto& r = op.u.rays;
             return ray_run(r.extrinsics, r.intrinsics, r.n_cam, r.h, r.w, r.out_nchw, r.out_nhwc, r.nhwc_c, r.nhwc_c_off,
-                           r.nhwc_dtype, r.img_map, s);
+                           r.nhwc_dtype, r.img_map, r.mode, r.n_origin_octaves, r.n_dir_octaves, r.plucker, s);
         }
         case MVLDM_OP_POSTERIOR_SAMPLE: {
             const auto& q = op.u.posterior;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 }
 
 // ---- elementwise forward/backward --------------------------------------------------------------------
-enum { TE_SILU_BWD = 0, TE_ADD = 1, TE_GEGLU_FWD = 2, TE_GEGLU_BWD = 3 };
+enum { TE_SILU_BWD = 0, TE_ADD = 1, TE_GEGLU_FWD = 2, TE_GEGLU_BWD = 3, TE_GELU_BWD = 4 };
 
 // dx = dy * silu'(x)
 template <typename TX, typename T>
@@ -80,6 +80,12 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const TX* __restrict__ x,
         const float v = to_f32<TX>(x[i]), s = sigmoid_f(v);
         dx[i] = from_f32<T>(to_f32<T>(dy[i]) * s * (1.0f + v * (1.0f - s)));
     }
+}
+// dx = dy * gelu'(x)   (exact GELU of the ViT feed-forward)
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const TX* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dx[i] = from_f32<T>(to_f32<T>(dy[i]) * gelu_grad_f(to_f32<TX>(x[i])));
 }
 // a += b   (gradient accumulation where two consumers feed one tensor)
 template <typename T> __global__ __launch_bounds__(256) void add_kernel(T* __restrict__ a, const T* __restrict__ b, size_t nchunks) {
@@ -321,6 +327,14 @@ int train_eltwise_run(int op, const void* a, const void* b, void* out, size_t ro
                 return dispatch_dtype(a_dtype, [&](auto tx) {
                     using TX = decltype(tx);
                     hipLaunchKernelGGL((silu_bwd_kernel<TX, T>), dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const TX*>(a),
+                                       reinterpret_cast<const T*>(b), reinterpret_cast<T*>(out), n);
+                    return check_launch();
+                });
+            case TE_GELU_BWD:
+                MVLDM_REQUIRE(b, "gelu_bwd: null dy");
+                return dispatch_dtype(a_dtype, [&](auto tx) {
+                    using TX = decltype(tx);
+                    hipLaunchKernelGGL((gelu_bwd_kernel<TX, T>), dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const TX*>(a),
                                        reinterpret_cast<const T*>(b), reinterpret_cast<T*>(out), n);
                     return check_launch();
                 });

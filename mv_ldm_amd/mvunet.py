@@ -28,7 +28,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
-from .modules import (Attention, Builder, Conv2d, FeedForward, GroupNorm, LayerNorm, UNet2DConditionModel, _PackMixin,
+from .modules import (Attention, Builder, Conv2d, FeedForward, GroupNorm, LayerNorm, Linear, UNet2DConditionModel, _PackMixin,
                       _segments, eager_builder, weights_version)
 from .runtime import from_nhwc, get_compute_dtype, require_gpu, to_nhwc
 
@@ -46,7 +46,20 @@ class SpatialTransformer3DCfg:
     pos_enc: bool = False
 
 
-MultiViewAttentionCfg = SpatialTransformer3DCfg
+@dataclass
+class CrossAttentionCfg:
+    """src/model/denoiser/standard/transformer.py:13-22 (`name: standard`)"""
+    name: str = "standard"
+    num_heads: int = 8
+    num_layers: int = 1
+    d_dot: Optional[int] = None
+    d_mlp: Optional[int] = None
+    d_mlp_multiplier: Optional[int] = 1
+    downscale: int = 1
+    pos_enc: bool = False
+
+
+MultiViewAttentionCfg = SpatialTransformer3DCfg      # | CrossAttentionCfg (src/model/denoiser/attention.py:6)
 
 
 @dataclass
@@ -63,7 +76,7 @@ class UNet2DModelCfg:
 class MultiViewUNetCfg:
     name: str = "mv_unet"
     autoencoder: UNet2DModelCfg = field(default_factory=UNet2DModelCfg)
-    multi_view_attention: MultiViewAttentionCfg = field(default_factory=SpatialTransformer3DCfg)
+    multi_view_attention: object = field(default_factory=SpatialTransformer3DCfg)     # SpatialTransformer3DCfg | CrossAttentionCfg
     use_ray_encoding: bool = True
     encoder_conditioning: bool = True
     mid_conditioning: bool = True
@@ -152,11 +165,110 @@ class SpatialTransformer3D(nn.Module):
         return from_nhwc(y).reshape(bsz, v, c, h, w)
 
 
-def get_attn_blocks(cfg: MultiViewAttentionCfg, unet_blocks) -> nn.ModuleList:
+# ------------------------------------------------------------------------------------------ "standard" MV attention
+class _PreNorm(nn.Module):
+    """src/model/transformer/pre_norm.py:30-37 (keys `norm.*`, `fn.*`)"""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = LayerNorm(dim)
+        self.fn = fn
+
+
+class _ViTAttention(nn.Module, _PackMixin):
+    """src/model/transformer/attention.py:36-101, self-attention form: fused bias-free `to_qkv`, `to_out` = Sequential(Linear, Dropout)
+    unless heads == 1 and dim_head == dim (then identity)."""
+
+    def __init__(self, dim, heads, dim_head):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head, self.inner = heads, dim_head, inner
+        self.to_qkv = Linear(dim, 3 * inner, bias=False)
+        self.to_out = nn.Sequential(Linear(inner, dim), nn.Dropout(0.0)) if not (heads == 1 and dim_head == dim) else nn.Identity()
+
+
+class _ViTFeedForward(nn.Module):
+    """src/model/transformer/feed_forward.py:29-40: Linear -> GELU -> Dropout -> Linear -> Dropout (keys net.0, net.3)"""
+
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.net = nn.Sequential(Linear(dim, hidden), nn.GELU(), nn.Dropout(0.0), Linear(hidden, dim), nn.Dropout(0.0))
+
+
+class _ViTTransformer(nn.Module):
+    """src/model/transformer/transformer.py:33-69: x = attn(norm(x)) + x; x = ff(norm(x)) + x per layer"""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.ModuleList([_PreNorm(dim, _ViTAttention(dim, heads, dim_head)),
+                                                    _PreNorm(dim, _ViTFeedForward(dim, mlp_dim))]) for _ in range(depth)])
+
+
+class StandardTransformer(nn.Module):
+    """`StandardTransformer` (src/model/denoiser/standard/transformer.py:45-136): a pre-norm ViT stack over ALL views' tokens of
+    a scene -- no GroupNorm / projections / outer residual around it (the block's output replaces the feature map).
+    `downscale > 1` (strided conv, transposed conv, 7x7 refinement convs) is not in the kernel family and refused;
+    `pos_enc=True` raises NameError exactly like the reference (`cond_features` is undefined there, :102)."""
+
+    def __init__(self, cfg: CrossAttentionCfg, d_in: int, d_kv: Optional[int] = None):
+        super().__init__()
+        assert (cfg.d_mlp is None) != (cfg.d_mlp_multiplier is None), "Expected exactly one of d_mlp and d_mlp_multiplier"
+        if d_kv is not None:
+            raise NotImplementedError("StandardTransformer(d_kv=...): the reference never passes it (denoiser/attention.py:13-19)")
+        if cfg.downscale > 1:
+            raise NotImplementedError("StandardTransformer downscale > 1 (strided / transposed / 7x7 convs) is not on the released path")
+        self.cfg, self.pos_enc, self.num_heads, self.d_in = cfg, cfg.pos_enc, cfg.num_heads, d_in
+        self.transformer = _ViTTransformer(d_in, cfg.num_layers, cfg.num_heads, cfg.d_dot or d_in // cfg.num_heads,
+                                           cfg.d_mlp or d_in * cfg.d_mlp_multiplier)
+
+    def emit(self, b: Builder, x, groups: Sequence[int]):
+        """x: NHWC [sum(groups), h, w, C]; one attention segment per scene (all its views' tokens)"""
+        if self.pos_enc:
+            raise NameError("name 'cond_features' is not defined")     # standard/transformer.py:102
+        n, h, w, c = x.shape
+        assert n == sum(groups)
+        lens = [g * h * w for g in groups]
+        hs = x.view(n * h * w, c)
+        first = True
+        for i, (attn, ff) in enumerate(self.transformer.layers):
+            with b.scope(f"transformer.layers.{i}"):
+                a = attn.fn
+                n1 = attn.norm.emit(b, hs, name="attn.norm")
+                qkv = a.to_qkv.emit(b, n1, name="attn.to_qkv")
+                b.free(n1)
+                o = b.attention(qkv[:, :a.inner], qkv[:, a.inner:2 * a.inner], qkv[:, 2 * a.inner:], a.heads, a.dim_head,
+                                _segments(b, lens), lens, lens, name="attn.sdpa")
+                b.free(qkv)
+                if isinstance(a.to_out, nn.Identity):
+                    raise NotImplementedError("heads == 1 with dim_head == dim (no output projection)")
+                h1 = a.to_out[0].emit(b, o, residual=hs, name="attn.to_out")
+                b.free(o)
+                if not first:
+                    b.free(hs)
+                n2 = ff.norm.emit(b, h1, name="ff.norm")
+                g = ff.fn.net[0].emit(b, n2, epilogue=L.EPI_GELU, name="ff.net.0+gelu")
+                b.free(n2)
+                hs = ff.fn.net[3].emit(b, g, residual=h1, name="ff.net.3")
+                b.free(g)
+                b.free(h1)
+                first = False
+        return hs.view(n, h, w, c)
+
+    def forward(self, features):
+        bsz, v, c, h, w = features.shape
+        b = eager_builder(features)
+        y = self.emit(b, to_nhwc(features.reshape(bsz * v, c, h, w), b.dtype), [v] * bsz)
+        return from_nhwc(y).reshape(bsz, v, c, h, w)
+
+
+def get_attn_blocks(cfg, unet_blocks) -> nn.ModuleList:
     """src/model/denoiser/attention.py:8-27"""
+    if cfg.name == "standard":
+        return nn.ModuleList([StandardTransformer(cfg=cfg, d_in=block.resnets[-1].out_channels) for block in unet_blocks])
     if cfg.name == "spatial_transformer_3d":
         return nn.ModuleList([SpatialTransformer3D(cfg=cfg, d_in=block.resnets[-1].out_channels) for block in unet_blocks])
-    raise NotImplementedError(f"multi_view_attention '{cfg.name}' (only spatial_transformer_3d is on the released path)")
+    raise NotImplementedError(f"multi_view_attention '{cfg.name}': the reference's get_attn_blocks knows 'standard' and "
+                              "'spatial_transformer_3d' (src/model/denoiser/attention.py:12,21)")
 
 
 # ------------------------------------------------------------------------------------------ denoiser

@@ -296,8 +296,14 @@ def nchw_to_nhwc(src: torch.Tensor, dtype, dst: Optional[torch.Tensor] = None, c
     return dst
 
 
+def ray_channels(mode: int = 0, n_origin_octaves: int = 0, n_dir_octaves: int = 0) -> int:
+    return int(L.load(required=False).mvldm_ray_channels(mode, n_origin_octaves, n_dir_octaves)) if L.load(required=False) is not None else \
+        {0: 6, 1: (6 * n_origin_octaves or 3) + (6 * n_dir_octaves or 3), 2: 6 * (n_origin_octaves + n_dir_octaves)}[mode]
+
+
 def ray_encode(extrinsics: torch.Tensor, intrinsics: torch.Tensor, h: int, w: int, out_nchw: Optional[torch.Tensor] = None,
-               out_nhwc: Optional[torch.Tensor] = None, c_off: int = 0, img_map: Optional[torch.Tensor] = None):
+               out_nhwc: Optional[torch.Tensor] = None, c_off: int = 0, img_map: Optional[torch.Tensor] = None,
+               mode: int = 0, n_origin_octaves: int = 0, n_dir_octaves: int = 0, plucker: bool = False):
     """extrinsics fp32 `[n, 4, 4]` (camera-to-world), intrinsics fp32 `[n, 3, 3]` on the device -> per-pixel
     [origin | direction] of the `h x w` latent grid: fp32 `[n, 6, h, w]` and/or channels [c_off, c_off+6) of an NHWC
     buffer `[.., h, w, C]` (camera i -> image img_map[i])."""
@@ -305,10 +311,11 @@ def ray_encode(extrinsics: torch.Tensor, intrinsics: torch.Tensor, h: int, w: in
     assert extrinsics.is_cuda and extrinsics.dtype == torch.float32 and extrinsics.is_contiguous() and extrinsics.shape[1:] == (4, 4)
     assert intrinsics.dtype == torch.float32 and intrinsics.is_contiguous() and intrinsics.shape == (n, 3, 3)
     if out_nchw is None and out_nhwc is None:
-        out_nchw = torch.empty(n, 6, h, w, dtype=torch.float32, device=extrinsics.device)
+        out_nchw = torch.empty(n, ray_channels(mode, n_origin_octaves, n_dir_octaves), h, w, dtype=torch.float32, device=extrinsics.device)
     L.check(L.load().mvldm_ray_encode(extrinsics.data_ptr(), intrinsics.data_ptr(), n, h, w, ptr(out_nchw), ptr(out_nhwc),
                                       0 if out_nhwc is None else out_nhwc.shape[-1], c_off,
-                                      L.F32 if out_nhwc is None else dt(out_nhwc), ptr(img_map), stream()))
+                                      L.F32 if out_nhwc is None else dt(out_nhwc), ptr(img_map), mode, n_origin_octaves, n_dir_octaves,
+                                      int(plucker), stream()))
     return out_nchw if out_nchw is not None else out_nhwc
 
 

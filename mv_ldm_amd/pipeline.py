@@ -61,15 +61,52 @@ def absolute_to_relative_camera(tform, index: int):
     return torch.linalg.inv(ref) @ tform
 
 
-def ray_encode(ctx_extr, ctx_intr, tgt_extr, tgt_intr, hl: int, wl: int, device=None):
-    """[b, v_c+v_t, 6, hl, wl] fp32 on the GPU: ray origins then directions (raw; `use_ray_encoding`,
-    `srt_ray_encoding`, `use_plucker` all off in the released config) by the HIP kernel.
-    diffusion_wrapper.py:169-190,301-322"""
+@dataclass
+class RayEncodingCfg:
+    """the ray-encoding switches of `ModelCfg` (diffusion_wrapper.py:98-127; config/main.yaml:26-34,
+    config/experiment/baseline.yaml:46-52): released values = raw 3 + 3 channels"""
+    use_ray_encoding: bool = False        # PositionalEncoding (src/model/encodings/positional_encoding.py) on origins / directions
+    srt_ray_encoding: bool = False        # SRT RayEncoder (src/model/srt/layers.py:35-58)
+    use_plucker: bool = False             # origins <- origins x directions
+    num_origin_octaves: int = 15
+    num_direction_octaves: int = 15
+
+    @property
+    def mode(self) -> int:
+        from . import _lib as L
+        return L.RAYS_SRT if self.srt_ray_encoding else (L.RAYS_POSITIONAL if self.use_ray_encoding else L.RAYS_RAW)
+
+    @property
+    def octaves(self):
+        return (self.num_origin_octaves, self.num_direction_octaves) if (self.srt_ray_encoding or self.use_ray_encoding) else (0, 0)
+
+    @property
+    def channels(self) -> int:
+        no, nd = self.octaves
+        if self.srt_ray_encoding:
+            return 2 * (3 * no + 3 * nd)
+        if self.use_ray_encoding:
+            return (6 * no if no > 0 else 3) + (6 * nd if nd > 0 else 3)
+        return 6
+
+    def kernel_args(self) -> dict:
+        no, nd = self.octaves
+        return dict(mode=self.mode, n_origin_octaves=no, n_dir_octaves=nd, plucker=self.use_plucker)
+
+    def denoiser_in_channels(self, latent_channels: int = 4) -> int:
+        """latent + ray channels + mask (diffusion_wrapper.py:98-127)"""
+        return latent_channels + self.channels + 1
+
+
+def ray_encode(ctx_extr, ctx_intr, tgt_extr, tgt_intr, hl: int, wl: int, device=None, cfg: Optional[RayEncodingCfg] = None):
+    """[b, v_c+v_t, C, hl, wl] fp32 on the GPU by the HIP kernel: ray origins then directions, raw (C = 6: the released
+    config) or through the positional / SRT encodings of `cfg`.  diffusion_wrapper.py:169-190,301-322"""
+    cfg = cfg or RayEncodingCfg()
     dev = torch.device(device) if device is not None else (ctx_extr.device if ctx_extr.is_cuda else torch.device("cuda"))
     extr = torch.cat([ctx_extr, tgt_extr], dim=1).to(dev, torch.float32).contiguous()
     intr = torch.cat([ctx_intr, tgt_intr], dim=1).to(dev, torch.float32).contiguous()
     b, v = extr.shape[:2]
-    return ops.ray_encode(extr.view(b * v, 4, 4), intr.view(b * v, 3, 3), hl, wl).view(b, v, 6, hl, wl)
+    return ops.ray_encode(extr.view(b * v, 4, 4), intr.view(b * v, 3, 3), hl, wl, **cfg.kernel_args()).view(b, v, cfg.channels, hl, wl)
 
 
 def ray_encode_host(ctx_extr, ctx_intr, tgt_extr, tgt_intr, hl: int, wl: int):
@@ -94,9 +131,14 @@ class SamplerCfg:
 
 class MVLDMPipeline:
     def __init__(self, denoiser: MultiViewUNet, autoencoder: AutoencoderKL, scheduler: DDIMScheduler,
-                 cfg: Optional[SamplerCfg] = None):
+                 cfg: Optional[SamplerCfg] = None, rays: Optional[RayEncodingCfg] = None):
         self.denoiser, self.autoencoder, self.scheduler = denoiser, autoencoder, scheduler
         self.cfg = cfg or SamplerCfg()
+        self.rays = rays or RayEncodingCfg()
+        need = self.rays.denoiser_in_channels(denoiser.out_channels)
+        if denoiser.in_channels != need:
+            raise ValueError(f"denoiser built for {denoiser.in_channels} input channels, the ray encoding needs {need} "
+                             "(latent + rays + mask, diffusion_wrapper.py:98-127)")
         self._plans = {}
 
     @property
@@ -157,7 +199,7 @@ class MVLDMPipeline:
     def _compile(self, b: int, v_c: int, v_t: int, hl: int, wl: int, dtype, n_steps: int):
         sch = self.scheduler
         key = (b, v_c, v_t, hl, wl, dtype, n_steps, self.cfg.use_cfg, self.cfg.cfg_scale, str(self.device),
-               tuple(int(t) for t in sch.timesteps), sch.clip_range)
+               tuple(int(t) for t in sch.timesteps), sch.clip_range, tuple(sorted(self.rays.kernel_args().items())))
         st = self._plans.get(key)
         if st is not None and st["weights_version"] == self.denoiser.weights_version():
             return st
@@ -206,7 +248,7 @@ class MVLDMPipeline:
         for rows in ((cond_img, unc_img) if use_cfg else (cond_img,)):
             ld.nchw_to_nhwc(x_T, unet_in, 0, img_map=rows, name="x_T")
             ld.nchw_to_nhwc(ones, unet_in, lc, img_map=rows, name="target mask")
-        ld.ray_encode(extr, intr, hl, wl, unet_in, lc + 1, name="ray grid")
+        ld.ray_encode(extr, intr, hl, wl, unet_in, lc + 1, name="ray grid", **self.rays.kernel_args())
         ld.nchw_to_nhwc(x_T, x_state, 0, name="x_T -> fp32 state")
         loader = ld.finalize(autotune=False)
         st = dict(plan=plan, loader=loader, unet_in=unet_in, x_state=x_state, eps=eps, timesteps=timesteps, cond_img=cond_img,

@@ -303,7 +303,8 @@ class Builder:
         self._emit(op, name, 0.0, src.numel() * 4 + src.numel() * dst.element_size(), (src, dst, img_map))
         return dst
 
-    def ray_encode(self, extr, intr, h, w, out_nhwc, c_off, img_map=None, out_nchw=None, name="ray_encode"):
+    def ray_encode(self, extr, intr, h, w, out_nhwc, c_off, img_map=None, out_nchw=None, name="ray_encode", mode=0, n_origin_octaves=0,
+                   n_dir_octaves=0, plucker=False):
         """extr fp32 [n,4,4], intr fp32 [n,3,3] device buffers (filled by the caller before each run)"""
         op = L.Op()
         op.kind = L.OP_RAY_ENCODE
@@ -311,6 +312,7 @@ class Builder:
         r.extrinsics, r.intrinsics, r.out_nchw, r.out_nhwc, r.img_map = ptr(extr), ptr(intr), ptr(out_nchw), ptr(out_nhwc), ptr(img_map)
         r.n_cam, r.h, r.w = extr.shape[0], h, w
         r.nhwc_c, r.nhwc_c_off, r.nhwc_dtype = (0, 0, L.F32) if out_nhwc is None else (out_nhwc.shape[-1], c_off, dt(out_nhwc))
+        r.mode, r.n_origin_octaves, r.n_dir_octaves, r.plucker = mode, n_origin_octaves, n_dir_octaves, int(plucker)
         self._emit(op, name, 0.0, extr.shape[0] * h * w * 6 * 4.0, (extr, intr, out_nhwc, out_nchw, img_map))
 
     def posterior_sample(self, moments, noise, out, scale=1.0, name="posterior_sample"):

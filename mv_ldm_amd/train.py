@@ -51,7 +51,7 @@ class FlatParams:
         self.module = module
         self.params = [p for p in module.parameters() if id(p) not in skip and p.requires_grad]
         self.excluded = [p for p in module.parameters() if id(p) in skip]
-        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), "FlatParams needs fp32 parameters on the GPU"
+        assert self.params and all(p.dtype == torch.float32 for p in self.params), "FlatParams needs fp32 master parameters"
         self.offset: Dict[int, int] = {}
         off = 0
         for p in self.params:
@@ -441,6 +441,25 @@ class TrainBuilder(Builder):
         self.tape.append(backward)
         return y
 
+    def t_gelu(self, x, name="gelu"):
+        """exact GELU as its own op (the inference path fuses it into the GEMM epilogue; training keeps the pre-activation)"""
+        y = self.empty(*x.shape)
+        op = L.Op()
+        op.kind = L.OP_ELTWISE
+        e = op.u.eltwise
+        e.x, e.y, e.n, e.op, e.src_dtype, e.dst_dtype = ptr(x), ptr(y), x.numel(), L.ELT_GELU, dt(x), dt(y)
+        self._emit(op, name, 0.0, 2.0 * x.numel() * x.element_size(), (x, y))
+
+        def backward():
+            dy = self.pop_grad(y)
+            if dy is None:
+                return
+            dx = self.empty(*x.shape)
+            self._elt(L.TE_GELU_BWD, x, dy, dx, 1, x.numel(), "bwd/" + name)
+            self.add_grad(x, dx)
+        self.tape.append(backward)
+        return y
+
     def t_geglu(self, ag, name="geglu"):
         rows, d2 = ag.shape
         h = self.empty(rows, d2 // 2)
@@ -524,8 +543,32 @@ def _t_transformer2d(b: TrainBuilder, t, x, name):
         return out.view(n, h, w, c)
 
 
+def _t_standard_block(b: TrainBuilder, m, x, groups, name):
+    """StandardTransformer (standard/transformer.py:45-136): pre-norm ViT layers over all views' tokens of a scene"""
+    n, h, w, c = x.shape
+    lens = [g * h * w for g in groups]
+    hs = x.view(n * h * w, c)
+    with b.scope(name):
+        for i, (attn, ff) in enumerate(m.transformer.layers):
+            with b.scope(f"transformer.layers.{i}"):
+                a = attn.fn
+                n1 = b.t_layernorm(hs, attn.norm, name="attn.norm")
+                qkv = b.t_linear(n1, [a.to_qkv.weight], None, name="attn.to_qkv")
+                o = b.t_attention(qkv, a.heads, a.dim_head, _segments(b, lens), lens, name="attn.sdpa")
+                h1 = b.t_linear(o, [a.to_out[0].weight], [[a.to_out[0].bias]], residual=hs, name="attn.to_out")
+                n2 = b.t_layernorm(h1, ff.norm, name="ff.norm")
+                l0, l3 = ff.fn.net[0], ff.fn.net[3]
+                pre = b.t_linear(n2, [l0.weight], [[l0.bias]], name="ff.net.0")
+                g = b.t_gelu(pre, name="ff.gelu")
+                hs = b.t_linear(g, [l3.weight], [[l3.bias]], residual=h1, name="ff.net.3")
+    return hs.view(n, h, w, c)
+
+
 def _t_mv_block(b: TrainBuilder, m, x, groups, name):
     """SpatialTransformer3D (mvdream/attention.py:371-439)"""
+    from .mvunet import StandardTransformer
+    if isinstance(m, StandardTransformer):
+        return _t_standard_block(b, m, x, groups, name)
     n, h, w, c = x.shape
     tokens = h * w
     with b.scope(name):
@@ -619,7 +662,7 @@ class TrainPlan:
     shape = (b scenes, v_c context views [0 = unconditional], v_t target views, hl, wl)."""
 
     def __init__(self, den, flat: FlatParams, b: int, v_c: int, v_t: int, hl: int, wl: int, dtype, loss_scale: float = 1.0,
-                 grad_scale: float = 1.0, graph: bool = False):
+                 grad_scale: float = 1.0, graph: bool = False, rays=None):
         dev = flat.flat.device
         self.shape = (b, v_c, v_t, hl, wl)
         v = v_c + v_t
@@ -649,7 +692,7 @@ class TrainPlan:
             a.n, a.c, a.hw, a.dst_c, a.dst_c_off, a.dst_dtype = n_img, lc, hl * wl, c_pad, 0, dt(unet_in)
             bld._emit(op, "add_noise -> latent channels", 0.0, 3.0 * self.latents.numel() * 4, (self.latents, self.noise_all, self.coef, unet_in))
             bld.nchw_to_nhwc(ones, unet_in, lc, img_map=tgt_img, name="target mask")
-            bld.ray_encode(self.extr, self.intr, hl, wl, unet_in, lc + 1, name="ray grid")
+            bld.ray_encode(self.extr, self.intr, hl, wl, unet_in, lc + 1, name="ray grid", **({} if rays is None else rays.kernel_args()))
         with bld.scope("unet"):
             eps = emit_unet_train(bld, den, unet_in, self.timesteps, [v] * b)
         dc = (lc + e - 1) // e * e
@@ -845,10 +888,11 @@ class MVLDMTrainer:
     step every `accumulate_grad_batches` micro-batches."""
 
     def __init__(self, denoiser, autoencoder, scheduler, optimizer_cfg: OptimizerCfg = None, train_cfg: TrainCfg = None,
-                 dtype=torch.bfloat16, world: int = 1, rank: int = 0, group=None, graph: bool = False, bucket_bytes: int = 256 << 20):
+                 dtype=torch.bfloat16, world: int = 1, rank: int = 0, group=None, graph: bool = False, bucket_bytes: int = 256 << 20,
+                 rays=None):
         self.denoiser, self.autoencoder, self.scheduler = denoiser, autoencoder, scheduler
         self.cfg = train_cfg or TrainCfg()
-        self.dtype, self.world, self.rank, self.graph = dtype, world, rank, graph
+        self.dtype, self.world, self.rank, self.graph, self.rays = dtype, world, rank, graph, rays
         for p in autoencoder.parameters():           # freeze.autoencoder = true (config/main.yaml:20)
             p.requires_grad_(False)
         self.flat = _flat_padded(denoiser, world)
@@ -868,7 +912,7 @@ class MVLDMTrainer:
             use_graph = self.graph and self.world == 1
             saved = self.flat.grad.clone() if use_graph else None       # a plan recorded mid-accumulation must not disturb it
             tp = TrainPlan(self.denoiser, self.flat, b, v_c, v_t, hl, wl, self.dtype, loss_scale=1.0 / acc,
-                           grad_scale=1.0 / (acc * self.world), graph=use_graph)
+                           grad_scale=1.0 / (acc * self.world), graph=use_graph, rays=self.rays)
             if saved is not None:
                 self.flat.grad.copy_(saved)
                 tp.loss.zero_()

@@ -118,8 +118,11 @@ class SpatialTransformer3D(nn.Module):
         return x.reshape(b, v, c, h, w)
 
 
-def get_attn_blocks(cfg: MVAttnCfg, unet_blocks) -> nn.ModuleList:
-    """src/model/denoiser/attention.py:8-27 (spatial_transformer_3d branch)."""
+def get_attn_blocks(cfg, unet_blocks) -> nn.ModuleList:
+    """src/model/denoiser/attention.py:8-27."""
+    if cfg.name == "standard":
+        from .standard import StandardTransformer
+        return nn.ModuleList([StandardTransformer(cfg, blk.resnets[-1].out_channels) for blk in unet_blocks])
     if cfg.name != "spatial_transformer_3d":
         raise NotImplementedError(cfg.name)
     return nn.ModuleList([SpatialTransformer3D(cfg, blk.resnets[-1].out_channels) for blk in unet_blocks])
@@ -141,7 +144,7 @@ class MVUNetCfg:
     """Mirror of `MultiViewUNetCfg` (mvunet.py:31-40).  `pretrained_overrides` is oracle-only: it
     lets tests build the SD-2.1 *topology* at reduced widths (no checkpoint is reachable)."""
     autoencoder: UNetCfg = field(default_factory=UNetCfg)
-    multi_view_attention: MVAttnCfg = field(default_factory=MVAttnCfg)
+    multi_view_attention: object = field(default_factory=MVAttnCfg)
     use_ray_encoding: bool = True
     encoder_conditioning: bool = True
     mid_conditioning: bool = True

@@ -371,8 +371,75 @@ def g9():
     save("g9_training_step", **out)
 
 
+# ----------------------------------------------------------------------------------------------- G10
+def g10():
+    """N4: the reference's `StandardTransformer` (src/model/denoiser/standard/transformer.py:45-136 over
+    src/model/transformer/{transformer,attention,feed_forward,pre_norm}.py), its MultiViewUNet walk with those blocks, and the
+    ray encodings of `DiffusionWrapper.ray_encode` (diffusion_wrapper.py:98-127,301-322: positional_encoding.py:8-36,
+    srt/layers.py:11-58, Pluecker).  transformer/attention.py:94 pins the CUDA-only EFFICIENT_ATTENTION SDPA backend:
+    replaced by a null context here (same arithmetic on the CPU math path)."""
+    import contextlib
+    R.install()
+    ST = R.ref("src.model.denoiser.standard.transformer")
+    TA = R.ref("src.model.transformer.attention")
+    TA.sdpa_kernel = lambda *a, **k: contextlib.nullcontext()
+    out = {}
+    cases = [(64, 8, 1, None, 1, 2, 3, 4), (128, 4, 2, 16, 2, 1, 5, 4), (320, 8, 1, None, 1, 1, 2, 8)]      # C, heads, layers, d_dot, mlp mult, b, V, h
+    for i, (C, heads, layers, d_dot, mult, b, V, h) in enumerate(cases):
+        cfg = ST.CrossAttentionCfg(name="standard", num_heads=heads, num_layers=layers, d_dot=d_dot, d_mlp=None, d_mlp_multiplier=mult)
+        m = ST.StandardTransformer(cfg, C).eval()
+        cs = load_seeded(m, 600 + i)
+        x = torch.randn(b, V, C, h, h, generator=torch.Generator().manual_seed(610 + i))
+        y = m(x)
+        out.update({f"st{i}_meta": np.array([C, heads, layers, -1 if d_dot is None else d_dot, mult, b, V, h, 600 + i]),
+                    f"st{i}_checksum": cs, f"st{i}_x": x, f"st{i}_y": y, f"st{i}_nkeys": len(m.state_dict())})
+        print(f"  g10 standard transformer {i}: C={C} heads={heads} layers={layers} -> |y| {y.abs().mean():.4f}")
+    out["n_st"] = len(cases)
+    # the reference's UNet walk with "standard" multi-view blocks (scratch topology, reduced width)
+    M = R.ref("src.model.denoiser.mvunet")
+    widths = [64, 64, 128, 128]
+    ae = M.UNet2DModelCfg(name="unet", down_block_types=["DownBlock2D"] * 4, mid_block_type="UNetMidBlock2D", up_block_types=["UpBlock2D"] * 4,
+                          only_cross_attention=False, block_out_channels=widths)
+    cfg = M.MultiViewUNetCfg(name="mv_unet", autoencoder=ae, multi_view_attention=ST.CrossAttentionCfg(
+        name="standard", num_heads=8, num_layers=1, d_dot=None, d_mlp=None, d_mlp_multiplier=1), pretrained_from=None)
+    m = M.MultiViewUNet(cfg, 11, 4).eval()
+    cs = load_seeded(m, 620)
+    g = torch.Generator().manual_seed(621)
+    x, t = torch.randn(1, 3, 11, 16, 16, generator=g), torch.tensor([[0, 400, 400]])
+    with R.cpu_cuda():
+        y = m.forward(x, t)
+    out.update({"unet_widths": np.array(widths), "unet_checksum": cs, "unet_nkeys": len(m.state_dict()), "unet_x": x, "unet_t": t, "unet_y": y})
+    print(f"  g10 mv-unet with standard blocks: |y| {y.abs().mean():.4f}")
+    # ray encodings through the reference's DiffusionWrapper.ray_encode
+    W = R.ref("src.model.diffusion_wrapper")
+    PE = R.ref("src.model.encodings.positional_encoding")
+    SRT = R.ref("src.model.srt.layers")
+    extr, intr = random_cameras(2, 3, seed=630)
+    extr = extr.roll(1, dims=1)
+    hl = 6
+    batch = {"context": {"extrinsics": extr[:, :1], "intrinsics": intr[:, :1]}, "target": {"extrinsics": extr[:, 1:], "intrinsics": intr[:, 1:]}}
+    modes = [("raw", False, False, False, 0, 0), ("plucker", False, False, True, 0, 0), ("positional", True, False, False, 4, 3),
+             ("positional_plucker_15", True, False, True, 15, 15), ("positional_dir_only", True, False, False, 0, 5), ("srt", False, True, False, 5, 2)]
+    for name, use_pe, srt, plucker, no, nd in modes:
+        w = W.DiffusionWrapper.__new__(W.DiffusionWrapper)
+        torch.nn.Module.__init__(w)
+        w.model_cfg = SimpleNamespace(use_plucker=plucker, srt_ray_encoding=srt, use_ray_encoding=use_pe)
+        if srt:
+            w.ray_encoder = SRT.RayEncoder(pos_octaves=no, ray_octaves=nd)
+        else:
+            w.ori_encoder = PE.PositionalEncoding(no) if (use_pe and no > 0) else torch.nn.Identity()
+            w.dir_encoder = PE.PositionalEncoding(nd) if (use_pe and nd > 0) else torch.nn.Identity()
+        with R.cpu_cuda():
+            enc = w.ray_encode(batch, torch.zeros(2, 1, 4, hl, hl), torch.zeros(2, 2, 4, hl, hl))
+        out[f"rays_{name}"] = enc
+        out[f"rays_{name}_cfg"] = np.array([int(use_pe), int(srt), int(plucker), no, nd])
+        print(f"  g10 rays {name}: {tuple(enc.shape)}")
+    out["rays_extr"], out["rays_intr"], out["rays_modes"] = extr, intr, np.array([m_[0] for m_ in modes])
+    save("g10_standard_and_encodings", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g9"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g9", "g10"]
     if "g1" in which:
         g1_g2()
     if "g3" in which:
@@ -385,6 +452,8 @@ if __name__ == "__main__":
         g6()
     if "g9" in which:
         g9()
+    if "g10" in which:
+        g10()
     if "g7" in which:
         from make_golden_schedules import g7
         g7()

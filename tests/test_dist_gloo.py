@@ -1,6 +1,8 @@
 """CPU, world_size 2, gloo: the N>1 path of the sampler -- scene sharding with no data-path collective,
 MAX-over-ranks timing, result bookkeeping (bench.py uses the same helpers over RCCL)."""
 import os
+
+import numpy as np
 import socket
 
 import torch
@@ -123,3 +125,95 @@ def test_two_ranks_together_produce_exactly_the_frames_of_one():
     # the same schedule with a different seed gives different frames (the per-call noise is really used)
     other = run_schedule(_StubPipeline(), calls, img, noise_seed=12)
     assert not torch.equal(other[1], want[1])
+
+
+# ---- DDP training: bucketed reduce-scatter / sharded AdamW / all-gather (training row) ---------------------
+def _torch_update(p, g, m, v, lr, betas, eps, wd, step, norm):
+    """test stand-in for mvldm_adamw_step (same arithmetic in torch; there is no CPU product path)"""
+    gi = g * norm[1]
+    p.mul_(1 - lr * wd)
+    m.mul_(betas[0]).add_(gi, alpha=1 - betas[0])
+    v.mul_(betas[1]).addcmul_(gi, gi, value=1 - betas[1])
+    bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
+    p.addcdiv_(m, v.sqrt() / bc2 ** 0.5 + eps, value=-lr / bc1)
+
+
+def _torch_clip(sumsq, max_norm, norm_out):
+    total = sumsq.sqrt()
+    norm_out[0:1] = total
+    norm_out[1:2] = torch.clamp(max_norm / (total + 1e-6), max=1.0) if max_norm > 0 else 1.0
+
+
+def _grad_mask(flat):
+    """1 at the positions parameters occupy, 0 in the alignment gaps / tail padding (real gradients never touch those)"""
+    m = torch.zeros(flat.numel)
+    for q in flat.params:
+        m[flat.offset[id(q)]:flat.offset[id(q)] + q.numel()] = 1.0
+    return m
+
+
+def _toy_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.Linear(64, 51, bias=False), torch.nn.LayerNorm(51), torch.nn.Linear(51, 10))
+
+
+def _ddp_worker(rank, world, port, q):
+    from mv_ldm_amd.train import DistributedOptimizer, OptimizerCfg, _flat_padded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _toy_model()
+    model.pretrained_from = None
+    flat = _flat_padded(model, world)
+    opt = DistributedOptimizer(flat, OptimizerCfg(lr=1e-2, scheduler={"name": "LinearLR", "kwargs": {"start_factor": 0.5, "total_iters": 2}}),
+                               world, rank, bucket_bytes=4096, max_norm=0.1, update=_torch_update,
+                               sumsq=lambda g: (g.double() ** 2).sum().float().reshape(1), clip=_torch_clip)
+    assert len(opt.buckets) > 3 and all((b - a) % (world * 4) == 0 for a, b in opt.buckets)
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        flat.grad.copy_(torch.randn(flat.numel, generator=g) * 0.01 * _grad_mask(flat))      # this rank's gradients (the loss carries 1/world)
+        for k in reversed(range(len(opt.buckets))):                         # the order the backward pass completes them
+            opt.reduce_bucket(k)
+        opt.step()
+    q.put((rank, flat.flat.numpy().copy(), float(opt.norm[0]), opt.step_count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_single_process_adamw_world2():
+    from mv_ldm_amd.train import _flat_padded, bucket_cut_points, make_buckets
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process: the same three steps on the SUMMED gradients with torch.optim.AdamW + clip_grad_norm_ + LinearLR
+    model = _toy_model()
+    model.pretrained_from = None
+    flat = _flat_padded(model, world)
+    params = list(model.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-2)
+    sch = torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.5, total_iters=2)
+    for step in range(3):
+        tot = sum(torch.randn(flat.numel, generator=torch.Generator().manual_seed(100 * step + r)) * 0.01 for r in range(world))
+        flat.grad.copy_(tot * _grad_mask(flat))
+        norm = torch.nn.utils.clip_grad_norm_(params, 0.1)
+        opt.step()
+        sch.step()
+    n_real = sum(p.numel() for p in params)
+    for rank, w, total, steps in got:
+        assert steps == 3 and abs(total - float(norm)) < 1e-5 * float(norm)
+        assert np.allclose(w, got[0][1])                                             # all-gather: every rank holds the same weights
+        live = flat.flat.detach().numpy()
+        assert np.abs(w - live).max() < 2e-6, np.abs(w - live).max()                 # == the unsharded optimizer
+    assert n_real <= flat.numel < n_real + 64
+    # bucket readiness: a bucket is cut right after the last plan op that writes a gradient inside it
+    buckets = make_buckets(64, 2, 16)
+    assert buckets == [(0, 16), (16, 32), (32, 48), (48, 64)]
+    cuts = bucket_cut_points([(10, 50), (11, 40), (20, 20), (21, 17), (30, 3)], buckets, 40)
+    assert cuts == [(3, 11), (2, 12), (1, 22), (0, 31)]

@@ -26,6 +26,7 @@ def test_default_config_holds_the_released_values():
     c = G.DEFAULT_CONFIG
     assert c["model"]["use_cfg"] is True and c["model"]["cfg_scale"] == 3.0                       # config/main.yaml:30-31
     assert c["model"]["scheduler"]["num_inference_steps"] == 70 and c["model"]["scheduler"]["kwargs"]["clip_sample"] is False
+    assert c["model"]["ray_encodings"] == {"num_origin_octaves": 15, "num_direction_octaves": 15}
     assert c["model"]["denoiser"]["multi_view_attention"] == {"name": "spatial_transformer_3d", "num_heads": 8, "num_layers": 1,
                                                               "d_mlp_multiplier": 1, "pos_enc": False}
     assert c["test"] == {"sampling_mode": "anchored", "limit_frames": None, "num_anchors_views": 4, "output_dir": ""}
@@ -54,9 +55,16 @@ def test_build_pipeline_follows_the_config():
     assert pipe.denoiser.in_channels == 11 and pipe.denoiser.out_channels == 4
     assert hasattr(pipe.denoiser, "cross_attn_blocks_encoder") and not hasattr(pipe.denoiser, "cross_attn_blocks_mid")
     assert pipe.denoiser.cross_attn_blocks_encoder[0].transformer_blocks[0].attn1.heads == 8
+    # the alternative YAML selections: Pluecker origins keep 6 ray channels, positional encodings widen conv_in,
+    # `multi_view_attention: standard` swaps the multi-view blocks
     cfg["model"]["use_plucker"] = True
-    with pytest.raises(NotImplementedError):
-        G.build_pipeline(cfg, device="cpu", allow_random_init=True, overrides=SMALL)
+    p2, _ = G.build_pipeline(cfg, device="cpu", allow_random_init=True, overrides=SMALL)
+    assert p2.rays.use_plucker and p2.denoiser.in_channels == 11
+    cfg["model"].update(use_ray_encoding=True, ray_encodings={"num_origin_octaves": 10, "num_direction_octaves": 8})
+    cfg["model"]["denoiser"]["multi_view_attention"] = {"name": "standard", "num_heads": 8, "d_mlp_multiplier": 1, "pos_enc": False}
+    cfg["model"]["denoiser"]["pretrained_from"] = None
+    p3, _ = G.build_pipeline(cfg, device="cpu", allow_random_init=True, overrides=SMALL)
+    assert p3.denoiser.in_channels == 4 + 6 * 10 + 6 * 8 + 1 and type(p3.denoiser.cross_attn_blocks_encoder[0]).__name__ == "StandardTransformer"
 
 
 def test_synthetic_example_is_batched_example_shaped():
