@@ -19,6 +19,7 @@
 // reads); V tile row-major [64][DV+16] read back transposed by ds_read_b64_tr_b16 (f32: V^T [DV][65]).  Head dims are zero-padded to DP = roundup(d,16) / DV = roundup(d,32)
 // inside LDS only -- never in HBM.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -59,6 +60,17 @@ template <> struct AttnMma<f16_t> {
 
 constexpr int BQ = 128, BKV = 64;
 
+// Row pitch (elements) of the row-major 16-bit V tile read with ds_read_b64_tr_b16.  One half-wave of that read touches
+// 4 key rows x two 32-byte column pieces (16-lane groups gi = 0, 1): conflict-free needs the 8 pieces on 8 different bank
+// octets of the 64-bank array, i.e. the pitch in bytes = 64 or 192 (mod 256) -- rows at banks {0,16,32,48} (some order), the
+// second group 8 banks further.  (The first layout, 2*DV + 32 bytes, put row 3 of group 1 on the banks of row 0 of group 0:
+// SQ_LDS_BANK_CONFLICT = 40 % of the LDS-active cycles of the d = 40 kernel, profiles/r02_attention_pmc.json.)
+constexpr int v_pitch(int dv) {
+    int bytes = 2 * dv;
+    while (bytes % 256 != 64 && bytes % 256 != 192) bytes += 32;
+    return bytes / 2;
+}
+
 // position of key `t` (0..63) inside the V^T tile for 16-bit types: the 8 consecutive slots
 // [ks*16 + hi*8, +8) must hold the keys that S^T registers (ks&1)*8 .. +8 of block ks>>1 belong to.
 __device__ __forceinline__ int vt_pos16(int t) {
@@ -74,10 +86,17 @@ __device__ __forceinline__ int vt_pos16(int t) {
 // accumulates the softmax denominator sum_k p[k] in the otherwise idle output column `head_dim` -- the 32 v_add_f32
 // per tile and lane of the row sum disappear from the VALU, which is what bounds this kernel (PMC: 79 % VALU-busy,
 // 45 % MFMA-busy).  The denominator then sums the SAME rounded probabilities the numerator multiplies.
-template <typename T, int DP, bool ONES>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (DP <= 64 ? 4 : (DP <= 96 ? 3 : 2)) : 1))
+// QB (query blocks per wave, 1 | 2): with QB = 2 a wave owns TWO 32-query blocks.  Their chains are independent, so
+// inside ONE wave the softmax VALU work of block A (33 v_exp_f32 + ~80 other VALU per tile) issues under the QK^T MFMAs
+// of block B, and block B's under the PV MFMAs of block A -- the VALU and the matrix pipe were adding up per wave
+// (~480 + ~450 cycles per tile at d = 40) and only overlapped across waves.  K fragments / V transpose reads are shared
+// by the two blocks (half the LDS reads per flop), a workgroup covers 256 queries (half the K/V tile fills per flop).
+// Costs registers (two S / P / O / Q sets): 2 waves per SIMD, head dims <= 64 only.
+template <typename T, int DP, bool ONES, int QB>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (QB == 2 ? 2 : (DP <= 64 ? 4 : (DP <= 96 ? 3 : 2))) : 1))
 void attention_kernel(const AttnParams p) {
     static_assert(!ONES || sizeof(T) == 2, "ones column: 16-bit kernels only");
+    static_assert(QB == 1 || sizeof(T) == 2, "two query blocks per wave: 16-bit kernels only");
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int EPC = Elt<T>::EPC;
     constexpr int DV = (DP + 31) / 32 * 32;
@@ -88,9 +107,10 @@ void attention_kernel(const AttnParams p) {
     // lane i / element j receives element (i&3) of the 8-byte row piece addressed by lane 4j + (i>>2)
     // (measured on gfx950, tools/probe/tr_probe.hip), i.e. a [4 keys][16 d] block comes back as lane = d,
     // element = key.  Pitch = 2*DV + 32 bytes puts the 4 key rows of a group on disjoint banks.
-    constexpr int VP = F32 ? (BKV + 1) : (DV + 16);
+    constexpr int VP = F32 ? (BKV + 1) : v_pitch(DV);
     constexpr int NCH = DP / EPC;                      // 16-byte chunks per K/V row
     constexpr int NQ = F32 ? DP / 2 : DP / 16;         // Q fragments per lane
+    constexpr int WQ = BQ * QB;                        // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);
     T* Vt = Ks + BKV * KP;
@@ -107,36 +127,46 @@ void attention_kernel(const AttnParams p) {
     const int head = hs_ % p.heads;
     const int4 sg = reinterpret_cast<const int4*>(p.seg)[hs_ / p.heads];
     const int q_row0 = sg.x, q_len = sg.y, kv_row0 = sg.z, kv_len = sg.w;
-    if (qt * BQ >= q_len) return;  // uniform per workgroup
+    if (qt * WQ >= q_len) return;  // uniform per workgroup
     const int d = p.d;
 
     // ---- Q fragments -> registers ----
-    const int q_local = qt * BQ + wave * 32 + l31;
-    const bool q_ok = q_local < q_len;
-    const T* qp = reinterpret_cast<const T*>(p.q) + (size_t)(q_row0 + q_local) * p.ld_q + head * d;
-    typename std::conditional<F32, float, typename AttnMma<typename std::conditional<F32, bf16_t, T>::type>::Frag>::type qf[NQ];
-    if constexpr (F32) {
+    int q_local[QB];
+    bool q_ok[QB];
+    typename std::conditional<F32, float, typename AttnMma<typename std::conditional<F32, bf16_t, T>::type>::Frag>::type qf[QB][NQ];
 #pragma unroll
-        for (int kk = 0; kk < NQ; ++kk) {
-            const int dk = 2 * kk + hi;
-            qf[kk] = (q_ok && dk < d) ? qp[dk] : 0.f;
-        }
-    } else {
+    for (int qb = 0; qb < QB; ++qb) {
+        q_local[qb] = qt * WQ + (wave * QB + qb) * 32 + l31;
+        q_ok[qb] = q_local[qb] < q_len;
+        const T* qp = reinterpret_cast<const T*>(p.q) + (size_t)(q_row0 + q_local[qb]) * p.ld_q + head * d;
+        if constexpr (F32) {
 #pragma unroll
-        for (int kk = 0; kk < NQ; ++kk) {
-            const int dk = kk * 16 + hi * 8;
-            u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-            if (q_ok && dk < d) raw = *reinterpret_cast<const u32x4*>(qp + dk);
-            qf[kk] = __builtin_bit_cast(typename AttnMma<T>::Frag, raw);
+            for (int kk = 0; kk < NQ; ++kk) {
+                const int dk = 2 * kk + hi;
+                qf[qb][kk] = (q_ok[qb] && dk < d) ? qp[dk] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) {
+                const int dk = kk * 16 + hi * 8;
+                u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+                if (q_ok[qb] && dk < d) raw = *reinterpret_cast<const u32x4*>(qp + dk);
+                qf[qb][kk] = __builtin_bit_cast(typename AttnMma<T>::Frag, raw);
+            }
         }
     }
 
-    f32x16 o[NDB];
+    f32x16 o[QB][NDB];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY;
+        l_run[qb] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
+    }
 
     const T* kbase = reinterpret_cast<const T*>(p.k) + (size_t)kv_row0 * p.ld_k + head * d;
     const T* vbase = reinterpret_cast<const T*>(p.v) + (size_t)kv_row0 * p.ld_v + head * d;
@@ -200,6 +230,7 @@ void attention_kernel(const AttnParams p) {
         }
     };
     if (ntile > 0) load_tile(0);
+    const float c = p.scale_log2e;
 
     for (int kt = 0; kt < ntile; ++kt) {
         // ---- K / V^T tile kt is in registers (loaded during the previous tile's math): park it in LDS ----
@@ -207,67 +238,87 @@ void attention_kernel(const AttnParams p) {
         __syncthreads();
         if (kt + 1 < ntile) load_tile(kt + 1);   // next tile's global loads fly under this tile's MFMAs
 
-        // ---- S^T = K Q^T ----
-        f32x16 s[2];
+        // ---- S^T = K Q^T for every query block of the wave (the K fragment is read once per block pair) ----
+        f32x16 s[QB][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C of the first MFMA
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                s[qb][kb] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C of the first MFMA
             const T* krow = Ks + (kb * 32 + l31) * KP;
             if constexpr (F32) {
 #pragma unroll
                 for (int kk = 0; kk < NQ; ++kk)
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * kk + hi], qf[kk], s[kb], 0, 0, 0);
+                    s[0][kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * kk + hi], qf[0][kk], s[0][kb], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < NQ; ++kk) {
                     const auto a = *reinterpret_cast<const typename AttnMma<T>::Frag*>(krow + kk * 16 + hi * 8);
-                    s[kb] = AttnMma<T>::mma(a, qf[kk], s[kb]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) s[qb][kb] = AttnMma<T>::mma(a, qf[qb][kk], s[qb][kb]);
                 }
             }
         }
 
-        // ---- online softmax (per query = per lane column) ----
-        // raw scores stay unscaled: max is taken on them (scale > 0) and the scale rides in the exp2 argument,
-        // p = exp2(s*c - m*c): one fma + one exp per score.  Keys beyond kv_len exist only in the last tile.
-        if (kt == ntile - 1 && (kv_len & (BKV - 1)) != 0) {
+        const bool ragged = kt == ntile - 1 && (kv_len & (BKV - 1)) != 0;
+        typename std::conditional<F32, int, typename AttnMma<typename std::conditional<F32, bf16_t, T>::type>::Frag>::type pf[QB][4];
+        // online softmax, per query = per lane column, in two parts.  Raw scores stay unscaled: max is taken on them
+        // (scale > 0) and the scale rides in the exp2 argument, p = exp2(s*c - m*c): one fma + one exp per score.
+        // part 1 (`sm_max`): mask (last tile only), running max, rescale of O when the max moved (wave-uniform branch);
+        // part 2 (`sm_exp`): the 32 exponentials + conversion of P to the MFMA operand type -- branch-free, so that with
+        // QB = 2 it can be scheduled INTO the PV MFMAs of the other query block.
+        float mc[QB];
+        auto sm_max = [&](const int qb) {
+            if (ragged) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        s[qb][kb][r] = key < kv_len ? s[qb][kb][r] : -INFINITY;
+                    }
+            }
+            float mx = s[qb][0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);   // raw v_exp_f32: arguments are <= 0, no denormal-range fix-up needed
+            m_run[qb] = m_new;
+            mc[qb] = -m_new * c;
+            if constexpr (!ONES) l_run[qb] *= alpha;
+            if (!__all(alpha == 1.0f)) {   // once the running max has settled the O rescale is skipped (wave-uniform)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+            }
+        };
+        auto sm_exp = [&](const int qb) {
+            float rs = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kt * BKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    s[kb][r] = key < kv_len ? s[kb][r] : -INFINITY;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][r], c, mc[qb]));
+                    s[qb][kb][r] = pv;
+                    if constexpr (!ONES) rs += pv;
                 }
-        }
-        float mx = s[0][0];
+            if constexpr (!ONES) l_run[qb] += rs;
+            if constexpr (!F32) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float c = p.scale_log2e;
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // raw v_exp_f32: arguments are <= 0, no denormal-range fix-up needed
-        m_run = m_new;
-        const float mc = -m_new * c;
-        float rs = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, mc));
-                s[kb][r] = pv;
-                if constexpr (!ONES) rs += pv;
+                    for (int j = 0; j < 8; ++j) pf[qb][ks][j] = from_f32<T>(s[qb][ks >> 1][(ks & 1) * 8 + j]);
             }
-        if constexpr (!ONES) l_run = l_run * alpha + rs;
-        if (!__all(alpha == 1.0f)) {   // once the running max has settled the O rescale is skipped (wave-uniform)
-#pragma unroll
-            for (int db = 0; db < NDB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        }
+        };
 
-        // ---- O^T += V^T P^T ----
         if constexpr (F32) {
+            sm_max(0);
+            sm_exp(0);
+            // ---- O^T += V^T P^T ----
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
                 const T* vrow = Vt + (db * 32 + l31) * VP;
@@ -276,69 +327,90 @@ void attention_kernel(const AttnParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[key], s[kb][r], o[db], 0, 0, 0);
+                        o[0][db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[key], s[0][kb][r], o[0][db], 0, 0, 0);
                     }
             }
         } else {
-            typename AttnMma<T>::Frag pf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[ks][j] = from_f32<T>(s[ks >> 1][(ks & 1) * 8 + j]);
-
-            // source piece of this lane for the transpose read: key row 4*hi + (s>>2) (+8 for the upper half of
-            // the fragment), d columns (gi&1)*16 + 4*(s&3) .. +3, with gi = lane>>4, s = lane&15
+            // ---- O^T += V^T P^T: source piece of this lane for the transpose read: key row 4*hi + (s>>2) (+8 for the upper
+            // half of the fragment), d columns (gi&1)*16 + 4*(s&3) .. +3, with gi = lane>>4, s = lane&15
             const int gi = lane >> 4, sl = lane & 15;
             const T* vsrc = Vt + (4 * (gi >> 1) + (sl >> 2)) * VP + (gi & 1) * 16 + 4 * (sl & 3);
+            auto pv = [&](const int qb) {
 #pragma unroll
-            for (int db = 0; db < NDB; ++db) {
+                for (int db = 0; db < NDB; ++db) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const T* pa = vsrc + (ks * 16) * VP + db * 32;
-                    const auto lo = AttnMma<T>::tr_read(pa);
-                    const auto up = AttnMma<T>::tr_read(pa + 8 * VP);
-                    const typename AttnMma<T>::Frag a = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[db] = AttnMma<T>::mma(a, pf[ks], o[db]);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const T* pa = vsrc + (ks * 16) * VP + db * 32;
+                        const auto lo = AttnMma<T>::tr_read(pa);
+                        const auto up = AttnMma<T>::tr_read(pa + 8 * VP);
+                        const typename AttnMma<T>::Frag a = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[qb][db] = AttnMma<T>::mma(a, pf[qb][ks], o[qb][db]);
+                    }
                 }
+            };
+            if constexpr (QB == 1) {
+                sm_max(0);
+                sm_exp(0);
+                pv(0);
+            } else {
+                // block A's softmax runs while block B's QK^T MFMAs are still in the matrix pipe; block B's exponentials are
+                // then scheduled between the PV MFMAs of block A (one MFMA, then a slice of the ~100 VALU instructions)
+                sm_max(0);
+                sm_exp(0);
+                sm_max(1);
+                __builtin_amdgcn_sched_barrier(0);
+                pv(0);
+                sm_exp(1);
+#pragma unroll
+                for (int g = 0; g < NDB * 4; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                        // the fragment's two transpose reads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, (96 + NDB * 4 - 1) / (NDB * 4), 0);   // a slice of the VALU work
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                pv(1);
             }
         }
         __syncthreads();
     }
 
     // ---- normalise and write O[q][d] ----
-    float l_tot;
-    if constexpr (ONES) {
-        // output column d (hi = 0 lanes) / d + 4 (hi = 1 lanes) of O^T: both inside the ones chunk, both the full sum
-        l_tot = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float l_tot;
+        if constexpr (ONES) {
+            // output column d (hi = 0 lanes) / d + 4 (hi = 1 lanes) of O^T: both inside the ones chunk, both the full sum
+            l_tot = 0.f;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int q8 = 0; q8 < 4; ++q8)
+                    if (db * 32 + q8 * 8 == d) l_tot = o[qb][db][4 * q8];
+        } else {
+            l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        }
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (!q_ok[qb]) continue;
+        if (p.lse && hi == 0) p.lse[(size_t)head * p.lse_ld + q_row0 + q_local[qb]] = m_run[qb] * p.scale_log2e + __log2f(l_tot);   // P = exp2(s*c - lse)
+        T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local[qb]) * p.ld_o + head * d;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int q8 = 0; q8 < 4; ++q8)
-                if (db * 32 + q8 * 8 == d) l_tot = o[db][4 * q8];
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (!q_ok) return;
-    if (p.lse && hi == 0) p.lse[(size_t)head * p.lse_ld + q_row0 + q_local] = m_run * p.scale_log2e + __log2f(l_tot);   // P = exp2(s*c - lse)
-    T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local) * p.ld_o + head * d;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int dd = db * 32 + 8 * r4 + 4 * hi;
+                if (dd < d) {
+                    if constexpr (F32) {
+                        f32x4 w = {o[qb][db][r4 * 4 + 0] * inv, o[qb][db][r4 * 4 + 1] * inv, o[qb][db][r4 * 4 + 2] * inv, o[qb][db][r4 * 4 + 3] * inv};
+                        *reinterpret_cast<f32x4*>(op + dd) = w;
+                    } else {
+                        union { T e[4]; u32x2 raw; } w;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int dd = db * 32 + 8 * r4 + 4 * hi;
-            if (dd < d) {
-                if constexpr (F32) {
-                    f32x4 w = {o[db][r4 * 4 + 0] * inv, o[db][r4 * 4 + 1] * inv, o[db][r4 * 4 + 2] * inv, o[db][r4 * 4 + 3] * inv};
-                    *reinterpret_cast<f32x4*>(op + dd) = w;
-                } else {
-                    union { T e[4]; u32x2 raw; } w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w.e[e] = from_f32<T>(o[db][r4 * 4 + e] * inv);
-                    *reinterpret_cast<u32x2*>(op + dd) = w.raw;
+                        for (int e = 0; e < 4; ++e) w.e[e] = from_f32<T>(o[qb][db][r4 * 4 + e] * inv);
+                        *reinterpret_cast<u32x2*>(op + dd) = w.raw;
+                    }
                 }
             }
-        }
+    }
 }
 
 
@@ -420,13 +492,20 @@ template <typename T> static int launch_attn_wide(const AttnParams& p, int n_seg
     return check_launch();
 }
 
-template <typename T, int DP, bool ONES> static int launch_attn_k(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
+// MVLDM_ATTN_QB=2 selects the two-query-blocks-per-wave form where it applies (A/B knob).  Measured on MI355X at 64 scenes
+// (tools/attn_bench.py, profiles/r02_attention_pmc.json): 3-D attention 8 x 40 over 5120 keys 6.15 ms vs 6.34 ms with one
+// block (+3 %), per-view / SD self-attention -2...-6 %, the block-B-exponentials-between-block-A-MFMAs schedule 6.41 ms:
+// the kernel is bound by VALU issue (70 % VALU-active at 42 % MFMA-busy, 11 VALU instructions per MFMA at d = 40), which
+// neither sharing fragments nor re-ordering reduces.  Default: one block per wave.
+static const int kEnvAttnQB = getenv("MVLDM_ATTN_QB") ? atoi(getenv("MVLDM_ATTN_QB")) : 1;
+
+template <typename T, int DP, bool ONES, int QB> static int launch_attn_k(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int KP = F32 ? (DP + 1) : (DP + 8);
-    constexpr int VP = F32 ? (BKV + 1) : (DV + 16);
+    constexpr int VP = F32 ? (BKV + 1) : v_pitch(DV);
     constexpr int smem = (BKV * KP + (F32 ? DV * VP : BKV * VP)) * (int)sizeof(T);
-    auto kern = attention_kernel<T, DP, ONES>;
+    auto kern = attention_kernel<T, DP, ONES, QB>;
     static bool attr_done = false;
     if (!attr_done) {
         if (smem > 48 * 1024)
@@ -434,18 +513,28 @@ template <typename T, int DP, bool ONES> static int launch_attn_k(AttnParams p, 
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    p.nqt = (max_q_len + BQ - 1) / BQ;
+    p.nqt = (max_q_len + BQ * QB - 1) / (BQ * QB);
     p.remap = max_q_len <= 2048;
     dim3 grid(p.nqt * p.heads * n_seg);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     return check_launch();
 }
 
+template <typename T, int DP, bool ONES> static int launch_attn_q(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
+    // two query blocks per wave (256 queries per workgroup) for the narrow heads of the long sequences: needs enough query
+    // tiles to fill the chip with half as many workgroups
+    if constexpr (sizeof(T) == 2 && DP <= 64) {
+        const long wgs2 = (long)((max_q_len + 2 * BQ - 1) / (2 * BQ)) * p.heads * n_seg;
+        if (kEnvAttnQB == 2 && max_q_len >= 2 * BQ && wgs2 >= 512) return launch_attn_k<T, DP, ONES, 2>(p, n_seg, max_q_len, s);
+    }
+    return launch_attn_k<T, DP, ONES, 1>(p, n_seg, max_q_len, s);
+}
+
 template <typename T, int DP> static int launch_attn(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        if (p.d % 8 == 0 && p.d < DP) return launch_attn_k<T, DP, true>(p, n_seg, max_q_len, s);
+        if (p.d % 8 == 0 && p.d < DP) return launch_attn_q<T, DP, true>(p, n_seg, max_q_len, s);
     }
-    return launch_attn_k<T, DP, false>(p, n_seg, max_q_len, s);
+    return launch_attn_q<T, DP, false>(p, n_seg, max_q_len, s);
 }
 
 int attention_run(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v, int ld_o,

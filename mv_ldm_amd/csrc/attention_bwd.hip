@@ -51,12 +51,18 @@ template <> struct BwdMma<f16_t> {
 };
 
 constexpr int BR = 128, BS = 64;     // resident rows per workgroup, streamed rows per tile
+// transpose-read tile pitch: bytes = 64 or 192 (mod 256) keeps the 8 row pieces of a half-wave on distinct bank octets (attention.hip)
+constexpr int bwd_v_pitch(int dv) {
+    int bytes = 2 * dv;
+    while (bytes % 256 != 64 && bytes % 256 != 192) bytes += 32;
+    return bytes / 2;
+}
 
 template <typename T, int DP, int MODE>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdParams p) {
     constexpr int EPC = 8;
     constexpr int DV = (DP + 31) / 32 * 32, NDB = DV / 32;
-    constexpr int KP = DP + 8, VP = DV + 16;     // row pitches (elements): row-read layout / transpose-read layout
+    constexpr int KP = DP + 8, VP = bwd_v_pitch(DV);     // row pitches (elements): row-read layout / transpose-read layout
     constexpr int NCH = DP / EPC, NQ = DP / 16;
     constexpr int NST = (BS * NCH + 255) / 256;
     using Frag = typename BwdMma<T>::Frag;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void attention_bwd_ref_kernel(const AttnBwdPar
 
 template <typename T, int DP> static int launch_bwd_mfma(AttnBwdParams p, int n_seg, int max_q_len, int max_kv_len, hipStream_t s) {
     constexpr int DV = (DP + 31) / 32 * 32;
-    constexpr int smem = (2 * BS * (DP + 8) + 2 * BS * (DV + 16)) * 2 + 2 * BS * 4;
+    constexpr int smem = (2 * BS * (DP + 8) + 2 * BS * bwd_v_pitch(DV)) * 2 + 2 * BS * 4;
     static bool done = false;
     if (!done) {
         if (smem > 48 * 1024) {

@@ -99,7 +99,13 @@ __device__ __forceinline__ void epilogue_store(const IgemmParams& p, int m, int 
     // v already includes bias/row_bias/activation
     v *= p.out_scale;
     if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[(size_t)m * p.n_dst + n_dst_col]);
-    const size_t o = (size_t)m * p.dst_ld + n_dst_col;
+    size_t drow = (size_t)m;
+    if (p.scatter) {   // sub-pixel phase of a decomposed nearest-2x upsampling conv (the split-K reduce of a phase lands here)
+        const int img = m / p.hw_out, rem = m - img * p.hw_out;
+        const int i = rem / p.w_out, j = rem - i * p.w_out;
+        drow = ((size_t)img * (2 * p.h_out) + 2 * i + p.ph_y) * (size_t)(2 * p.w_out) + 2 * j + p.ph_x;
+    }
+    const size_t o = drow * p.dst_ld + n_dst_col;
     if (p.dst_f32) reinterpret_cast<float*>(p.dst)[o] = v;
     else reinterpret_cast<T*>(p.dst)[o] = from_f32<T>(v);
 }
@@ -1249,7 +1255,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     int splitk = d.splitk;
     MVLDM_REQUIRE(tile >= 0 && tile <= kNumTiles && splitk >= 0, "igemm: tile/splitk");
     choose_config(d, p.M, p.k_tiles, tile, splitk, d.workspace_bytes);
-    if (phase) splitk = 1;   // the four phases interleave in the output: no split-K slabs for them
+    // (a phase conv may split K like any other: its partial slabs are indexed by the LOW-resolution row and the reduce kernel scatters)
     if (splitk > 1)
         MVLDM_REQUIRE(d.workspace && (size_t)splitk * p.M * d.n_pad * sizeof(float) <= d.workspace_bytes,
                       "igemm: split-K workspace too small");
@@ -1292,7 +1298,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
                         2 * halo_rows_for(d.w_in) * 128 + 3 * 128 * 128 + 1152 <= 160 * 1024))
         tile = 7;   // the halo kernel only does 3x3 / stride 1 / pad 1 on images up to 63 pixels wide, one K pass
     if (phase) {
-        MVLDM_REQUIRE(p.use_bl && p.splitk == 1 && p.stage_epi, "igemm: 2x2 phase conv needs the lean 16-bit loop, one K pass, 8-aligned 16-bit output");
+        MVLDM_REQUIRE(p.use_bl && p.stage_epi, "igemm: 2x2 phase conv needs the lean 16-bit loop and an 8-aligned 16-bit output");
         if (tile != 7 && tile != 10) tile = 2;
     }
     if (p.use_bl && d.upsample == 1 && tile != 7) tile = 2;

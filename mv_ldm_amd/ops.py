@@ -187,13 +187,14 @@ def upsample_phase_weights(w: torch.Tensor) -> list:
     return out
 
 
-def conv2d_upsample_phases(x: torch.Tensor, pws, bias=None, tile=0) -> torch.Tensor:
+def conv2d_upsample_phases(x: torch.Tensor, pws, bias=None, tile=0, splitk=0) -> torch.Tensor:
     """x NHWC `[n, h, w, c]` (16-bit); `pws`: the 4 packed phase weights -> NHWC `[n, 2h, 2w, n_out]`"""
     n, h, w, _ = x.shape
     out = torch.empty(n, 2 * h, 2 * w, pws[0].n_out, dtype=x.dtype, device=x.device)
+    scratch = workspace(min(16 * n * h * w * pws[0].n_pad * 4, 256 << 20), x.device)
     for phase, pw in enumerate(pws):
         d = igemm_desc(x, None, pw, out, n_img=n, h_in=h, w_in=w, h_out=h, w_out=w, stride=1, pad=0, upsample=2 + phase,
-                       bias=bias, splitk=1, tile=tile)
+                       bias=bias, splitk=splitk, tile=tile, ws=scratch)
         L.check(L.load().mvldm_igemm_fwd(C.byref(d), stream()))
     return out
 

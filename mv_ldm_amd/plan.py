@@ -156,6 +156,7 @@ class Builder:
         """nearest-2x + 3x3 conv as four 2x2 phase convs on the low-resolution input (ops.upsample_phase_weights)"""
         n, h, w, c0 = x.shape
         out = self.empty(n, 2 * h, 2 * w, pws[0].n_out, dtype=x.dtype)
+        ws = self.splitk_ws()        # small batches: K = 4C is long and there are few output tiles -- let the library split K
         for phase, pw in enumerate(pws):
             assert pw.ksize == 2 and pw.k_order == 1 and c0 == pw.c_pad
             op = L.Op()
@@ -169,10 +170,10 @@ class Builder:
             d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
             d.row_bias_ld = 0
             d.epilogue, d.act_dtype, d.dst_dtype = L.EPI_NONE, dt(x), dt(out)
-            d.splitk, d.tile, d.out_scale = 1, 0, 1.0
+            d.splitk, d.tile, d.out_scale = 0, 0, 1.0
             d.dst_ld = 0
             d.k_order = 1
-            d.workspace, d.workspace_bytes = None, 0
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
             m = n * h * w
             es = x.element_size()
             nbytes = (pw.n_out * 4 * c0 + (m * c0 if phase == 0 else 0)) * es + m * pw.n_out * es

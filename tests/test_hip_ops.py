@@ -413,6 +413,10 @@ def test_upsample_conv_as_four_phase_convs(ops, dtype, n, c, cout, h, w, tile):
     close(nchw(y), ref, dtype, "phases")
     y_gather = ops.conv2d(nhwc(x, dtype), ops.pack_weight(wt.cuda(), dtype), b.cuda(), upsample=True)
     close(nchw(y), nchw(y_gather), dtype, "phases vs gather")
+    # small batches split K (K = 4C over few output tiles): partial slabs by low-resolution row, scattered by the reduce kernel
+    for sk in (1, 3):
+        ys = ops.conv2d_upsample_phases(nhwc(x, dtype), pws, b.cuda(), tile=tile, splitk=sk)
+        close(nchw(ys), ref, dtype, f"phases, split-K {sk}")
 
 
 def test_ddim_clip_sample_and_step_clamp_bit_exact(ops):
