@@ -1334,10 +1334,17 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     return MVLDM_OK;
 }
 
+// tile 12: the persistent, epilogue-pipelined Linear kernel of linear_pp.hip
+int linear_pp_run(const mvldm_igemm_desc& d, hipStream_t s);
+
 int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
     IgemmParams p;
     int tile = 0;
     if (d.n_img == 0 || d.h_out == 0 || d.w_out == 0) return MVLDM_OK;   // empty batch: nothing to do (its buffers may be null)
+    if ((d.tile & 15) == 12) {
+        MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
+        return linear_pp_run(d, s);
+    }
     int rc = fill_params(d, p, tile);
     if (rc) return rc;
     if (p.M == 0) return MVLDM_OK;

@@ -342,7 +342,7 @@ class Builder:
 # tile on its own buffers (they hold scratch at that point) and the fastest is frozen into the descriptor.
 # Results are cached per problem signature for the life of the process.  MVLDM_AUTOTUNE=0 keeps the rules.
 _TUNE_CACHE = {}
-_TUNE_TILES = (0, 1, 2, 3, 6, 7, 8, 9, 10, 11)
+_TUNE_TILES = (0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12)
 
 
 def _igemm_signature(d) -> tuple:

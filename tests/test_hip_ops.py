@@ -185,6 +185,54 @@ def test_geglu(ops, dtype, rows, c):
             close(y.float().cpu().double(), ref, dtype, f"geglu tile{tile}")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,cin,cout", [(300, 320, 320), (1000, 384, 960), (2500, 640, 200), (70000, 320, 64), (20000, 1280, 328)])
+def test_linear_persistent_tile(ops, dtype, rows, cin, cout):
+    """tile 12 (linear_pp.hip: persistent workgroups, the epilogue of a tile runs under the next tile's main loop): every
+    epilogue it carries, ragged M / N, more tiles than workgroups (70000 rows -> 274 tiles on <= 256 workgroups)"""
+    x, wt = rnd((rows, cin), 41, dtype), rnd((cout, cin), 42, dtype, 1 / math.sqrt(cin))
+    b = torch.randn(cout, generator=G(43)) * 0.1
+    res = rnd((rows, cout), 44, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    lin = F.linear(x.double(), wt.double(), b.double())
+    xg = x.to(dtype).cuda()
+    y = ops.linear(xg, pw, b.cuda(), residual=res.to(dtype).cuda(), tile=12)
+    close(y.float().cpu().double(), lin + res.double(), dtype, "linear+res tile12")
+    y = ops.linear(xg, pw, None, tile=12)
+    close(y.float().cpu().double(), F.linear(x.double(), wt.double()), dtype, "linear nobias tile12")
+    y = ops.linear(xg, pw, b.cuda(), epilogue=1, tile=12)
+    close(y.float().cpu().double(), F.silu(lin), dtype, "linear silu tile12")
+    y = ops.linear(xg, pw, b.cuda(), epilogue=3, tile=12)
+    close(y.float().cpu().double(), F.gelu(lin), dtype, "linear gelu tile12")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,c", [(300, 320), (33000, 320), (5000, 640)])
+def test_geglu_persistent_tile(ops, dtype, rows, c):
+    x, wt = rnd((rows, c), 45, dtype), rnd((8 * c, c), 46, dtype, 1 / math.sqrt(c))
+    b = torch.randn(8 * c, generator=G(47)) * 0.1
+    pw = ops.pack_weight(wt.cuda(), dtype, geglu=True)
+    a, g = F.linear(x.double(), wt.double(), b.double()).chunk(2, -1)
+    y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=12)
+    assert y.shape == (rows, 4 * c)
+    close(y.float().cpu().double(), a * F.gelu(g), dtype, "geglu tile12")
+    y7 = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=7)      # same MFMA K order; the bias enters first here, last there
+    assert (y.float() - y7.float()).abs().max().item() <= 2e-2 * y7.float().abs().max().item()
+    assert (y != y7).float().mean().item() < 0.05
+
+
+def test_persistent_tile_refuses_what_it_cannot_do(ops):
+    """tile 12 is Linear-only (1x1, one source, K a multiple of 64 and >= 320): anything else is an error, not a silent fallback"""
+    import mv_ldm_amd._lib as L
+    x = torch.randn(2, 8, 8, 64, device="cuda").to(torch.bfloat16)
+    pw3 = ops.pack_weight(torch.randn(64, 64, 3, 3, device="cuda"), torch.bfloat16)
+    with pytest.raises(L.MvldmError):
+        ops.conv2d(x, pw3, tile=12)
+    pw1 = ops.pack_weight(torch.randn(64, 256, device="cuda"), torch.bfloat16)
+    with pytest.raises(L.MvldmError):
+        ops.linear(torch.randn(128, 256, device="cuda").to(torch.bfloat16), pw1, tile=12)     # K = 256: 4 K-tiles, the epilogue needs 5 steps
+
+
 def test_pack_weight_layout(ops):
     w = torch.randn(70, 24, 3, 3, generator=G(24))
     pw = ops.pack_weight(w.cuda(), torch.float32)

@@ -1,0 +1,30 @@
+"""EXPERIMENT (wrong results by design): time tile 12 (linear_pp.hip) with operand traffic / stores switched off, to see what
+bounds its main loop.  Needs mv_ldm_amd/csrc/libmvldm_hip_exp.so = the library with linear_pp.hip compiled -DMVLDM_EXPERIMENTS
+(tools/lpp_probe.sh builds it).  python tools/lpp_probe.py <fake bits>  ->  one line per shape"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MVLDM_LPP_FAKE"] = sys.argv[1] if len(sys.argv) > 1 else "0"
+import torch
+import mv_ldm_amd._lib as L
+L.LIB_PATH = L.LIB_PATH.with_name("libmvldm_hip_exp.so")
+from mv_ldm_amd import ops
+
+n = 9 * 64
+SH = [("L0.geglu", n * 1024, 320, 2560, 2), ("L0.qkv", n * 1024, 320, 960, 0), ("L1.geglu", n * 256, 640, 5120, 2),
+      ("L2.geglu", n * 64, 1280, 10240, 2), ("L2.qkv", n * 64, 1280, 3840, 0)]
+out = []
+for name, rows, k, nn, epi in SH:
+    x = torch.randn(rows, k, device="cuda").to(torch.bfloat16)
+    w = torch.randn(nn, k, device="cuda") / k ** 0.5
+    pw = ops.pack_weight(w, torch.bfloat16, geglu=epi == 2)
+    b = torch.randn(nn, device="cuda")
+    f = lambda: ops.linear(x, pw, b, epilogue=epi, tile=12, splitk=1)
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    out.append(f"{name} {us:.0f}us {2.0 * rows * k * nn / us / 1e6:.0f}TF")
+print("fake", os.environ["MVLDM_LPP_FAKE"], " | ".join(out), flush=True)
