@@ -34,14 +34,24 @@ from .plan import Builder
 from .runtime import from_nhwc, get_compute_dtype, require_gpu, to_nhwc
 
 
+# Kernels that update parameters in place (train.py: fused AdamW on the flat buffers) do not move torch's version counters;
+# they call `bump_weights_epoch()` instead, and every pack / plan fingerprint below carries the epoch.
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch() -> int:
+    _WEIGHTS_EPOCH[0] += 1
+    return _WEIGHTS_EPOCH[0]
+
+
 def _ver(*params):
-    return tuple((p.data_ptr(), p._version, str(p.device)) for p in params if p is not None)
+    return (_WEIGHTS_EPOCH[0],) + tuple((p.data_ptr(), p._version, str(p.device)) for p in params if p is not None)
 
 
 def weights_version(module) -> int:
     """fingerprint of every parameter's (storage, in-place version): recorded plans hold raw pointers to PACKED copies of
     the weights, so they are keyed on this and re-recorded after `load_state_dict`, an optimizer step, an EMA copy ..."""
-    return hash(tuple((p.data_ptr(), p._version) for p in module.parameters()))
+    return hash((_WEIGHTS_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in module.parameters()))
 
 
 class _PackMixin:

@@ -74,8 +74,8 @@ class FlatParams:
 
     def bump(self):
         """in-place kernel updates do not move torch's version counters: recorded INFERENCE plans key on this instead"""
-        self.epoch += 1
-        self.module._weights_epoch = self.epoch
+        from .modules import bump_weights_epoch
+        self.epoch = bump_weights_epoch()
 
     def contiguous(self, ps: Sequence[nn.Parameter]) -> bool:
         o = [self.offset[id(p)] for p in ps]

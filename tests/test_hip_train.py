@@ -118,6 +118,31 @@ def test_accumulation_clipping_adamw_step_vs_oracle(golden):
     assert (num / den_) ** 0.5 < 2e-2, (num / den_) ** 0.5                        # AdamW normalises tiny gradients: 1/sqrt(v) amplifies noise
 
 
+def test_inference_plans_follow_in_place_optimizer_steps(golden):
+    """the fused AdamW kernel updates the flat fp32 parameters in place, invisible to torch's version counters: recorded
+    INFERENCE plans (raw pointers to PACKED weight copies) must be re-recorded after it (modules.bump_weights_epoch)"""
+    from mv_ldm_amd.train import OptimizerCfg
+    g = golden("g9_training_step")
+    tr = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-2))
+    den = tr.denoiser
+    batch, ch = g9_case(g, 0)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    lat = torch.randn(1, 3, 11, 16, 16, device="cuda", generator=gen)
+    ts = torch.tensor([10], device="cuda")
+
+    def fwd():
+        with torch.no_grad():
+            return den(lat, ts).float().clone()
+
+    y0 = fwd()
+    assert torch.equal(y0, fwd())                       # cached plan, same weights
+    for _ in range(2):                                  # accumulate_grad_batches = 2: the second call steps the optimizer
+        tr.training_step(batch, **hip_choices(ch))
+    assert tr.opt.step_count == 1
+    y1 = fwd()
+    assert float((y1 - y0).abs().max()) > 0, "inference plan still runs the pre-step packed weights"
+
+
 def test_full_width_training_step_runs_configs3_shape():
     """BASELINE.json configs[3] per-GPU micro-batch at FULL width: 4 scenes x (2 ctx + 3 tgt) views x 256x256, bf16: one
     accumulation window (2 micro-batches) + optimizer step; size-independent checks only (finite loss of the expected
