@@ -94,13 +94,15 @@ __device__ __forceinline__ int orig_col(int n_packed, int n_out, bool geglu) {
     return (blk & 1) ? (n_out >> 1) + (blk >> 1) * 32 + w : (blk >> 1) * 32 + w;
 }
 
-template <typename T>
+// SCATTER false: the per-element fallback epilogue inside the GEMM kernels -- phase convs never take it (fill_params), and with
+// the two divisions in its 64-fold unrolled body hipcc stops unrolling and demotes the accumulators to scratch
+template <typename T, bool SCATTER = false>
 __device__ __forceinline__ void epilogue_store(const IgemmParams& p, int m, int n_dst_col, float v) {
     // v already includes bias/row_bias/activation
     v *= p.out_scale;
     if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[(size_t)m * p.n_dst + n_dst_col]);
     size_t drow = (size_t)m;
-    if (p.scatter) {   // sub-pixel phase of a decomposed nearest-2x upsampling conv (the split-K reduce of a phase lands here)
+    if (SCATTER && p.scatter) {   // sub-pixel phase of a decomposed nearest-2x upsampling conv (the split-K reduce of a phase lands here)
         const int img = m / p.hw_out, rem = m - img * p.hw_out;
         const int i = rem / p.w_out, j = rem - i * p.w_out;
         drow = ((size_t)img * (2 * p.h_out) + 2 * i + p.ph_y) * (size_t)(2 * p.w_out) + 2 * j + p.ph_x;
@@ -307,17 +309,22 @@ __device__ __forceinline__ void epi_rows(const IgemmParams& p, const float* st, 
     }
 }
 
-template <typename T, int TN, int J0, int JN, int PITCH>
-__device__ __forceinline__ void epi_group(const IgemmParams& p, const f32x16 (&accrow)[TN], float* st, int m0, int pcol0, int split,
-                                          int mode, int lane) {
+// park JN column blocks (from J0) of row block I of the wave's accumulators: raw fp32, [row][col].  The accumulators are named by
+// template indices, never through a reference to a sub-array: with five epilogue modes behind it hipcc otherwise stops promoting
+// the 64 x 64 wave tile's `acc` to registers (320 bytes of scratch per lane, written and re-read once per tile: 3-4x slower)
+template <int TM, int TN, int I, int J0, int JN, int PITCH>
+__device__ __forceinline__ void epi_park(const f32x16 (&acc)[TM][TN], float* st, int lane) {
     const int hi = lane >> 5, l31 = lane & 31;
-    // ---- park: raw accumulators, fp32, [row][col] ----
 #pragma unroll
     for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + j * 32 + l31] = accrow[J0 + j][r];
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hi) * PITCH + j * 32 + l31] = acc[I][J0 + j][r];
     // (same wave wrote and reads: LDS serves a wave's requests in order; the compiler's own lgkmcnt wait covers
     //  the data dependence through `st`)
+}
+
+template <typename T, int JN, int PITCH>
+__device__ __forceinline__ void epi_group_rows(const IgemmParams& p, const float* st, int m0, int pcol0, int split, int mode, int lane) {
     if (mode == EPI_PARTIAL) epi_rows<T, JN, EPI_PARTIAL, PITCH>(p, st, m0, pcol0, split, lane);
     else if (mode == EPI_PAIR_GEGLU) {
         if constexpr (JN % 2 == 0) epi_rows<T, JN, EPI_PAIR_GEGLU, PITCH>(p, st, m0, pcol0, split, lane);
@@ -326,11 +333,28 @@ __device__ __forceinline__ void epi_group(const IgemmParams& p, const f32x16 (&a
     else epi_rows<T, JN, EPI_PLAIN, PITCH>(p, st, m0, pcol0, split, lane);
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int I>
+__device__ __forceinline__ void igemm_epilogue_rowblock(const IgemmParams& p, const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* st, int tm, int tn,
+                                                        int split, int wm, int wn, int mode, int lane) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int WCOLS = BN / WN;          // packed columns of a wave tile
+    constexpr int JG = park_blocks(TN);
+    constexpr int PITCH = JG * 32 + 4;      // floats
+    const int m0 = tm * BM + wm * (BM / WM) + I * 32;
+    const int pcol0 = tn * BN + wn * WCOLS;
+    epi_park<TM, TN, I, 0, JG, PITCH>(acc, st, lane);
+    epi_group_rows<T, JG, PITCH>(p, st, m0, pcol0, split, mode, lane);
+    if constexpr (TN > JG) {
+        epi_park<TM, TN, I, JG, TN - JG, PITCH>(acc, st, lane);
+        epi_group_rows<T, TN - JG, PITCH>(p, st, m0, pcol0 + JG * 32, split, mode, lane);
+    }
+    if constexpr (I + 1 < TM) igemm_epilogue_rowblock<T, BM, BN, WM, WN, I + 1>(p, acc, st, tm, tn, split, wm, wn, mode, lane);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tm,
                                                       int tn, int split, int wm, int wn, int wave, int lane, char* smem) {
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int WCOLS = BN / WN;          // packed columns of a wave tile
+    constexpr int TN = BN / WN / 32;
     constexpr int JG = park_blocks(TN);
     constexpr int PITCH = JG * 32 + 4;      // floats
     static_assert(TN <= 2 * JG, "at most two park groups");
@@ -340,13 +364,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IgemmParams& p, f32x
                                   : (p.epilogue == MVLDM_EPI_GEGLU ? EPI_PAIR_GEGLU
                                      : (p.epilogue == MVLDM_EPI_SILU ? EPI_ACT_SILU : (p.epilogue == MVLDM_EPI_GELU ? EPI_ACT_GELU : EPI_PLAIN)));
     __syncthreads();   // every wave is done with the operand ring
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m0 = tm * BM + wm * (BM / WM) + i * 32;
-        const int pcol0 = tn * BN + wn * WCOLS;
-        epi_group<T, TN, 0, JG, PITCH>(p, acc[i], st, m0, pcol0, split, mode, lane);
-        if constexpr (TN > JG) epi_group<T, TN, JG, TN - JG, PITCH>(p, acc[i], st, m0, pcol0 + JG * 32, split, mode, lane);
-    }
+    igemm_epilogue_rowblock<T, BM, BN, WM, WN, 0>(p, acc, st, tm, tn, split, wm, wn, mode, lane);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -977,7 +995,7 @@ template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce
             else if (p.epilogue == MVLDM_EPI_GELU) a = gelu_erf_fast(a);
             v = a;
         }
-        epilogue_store<T>(p, m, col, v);
+        epilogue_store<T, true>(p, m, col, v);
     }
 }
 

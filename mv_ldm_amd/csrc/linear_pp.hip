@@ -131,6 +131,12 @@ template <typename T> __device__ __forceinline__ typename LpMma<T>::Frag lp_frag
     return *reinterpret_cast<const typename LpMma<T>::Frag*>(tile + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
 }
 
+#ifdef MVLDM_EXPERIMENTS_NOGELU
+#define LP_GELU(x) (x)
+#else
+#define LP_GELU(x) gelu_erf_fast(x)
+#endif
+
 // epilogue-side coordinates of the finished tile, per lane (lane & 31 = row inside a 32-row block)
 struct LpEpi {
     unsigned row_dst[2], row_res[2];   // byte offset of this lane's row in dst / residual for row block i, kRowNone past M
@@ -165,7 +171,7 @@ __device__ __forceinline__ void lp_epi_compute(const LinPPParams& p, const f32x1
         }
     if constexpr (gate) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) gl[k] = gelu_erf_fast(c[k]);
+        for (int k = 0; k < 16; ++k) gl[k] = LP_GELU(c[k]);
         return;
     }
     if constexpr (GEGLU) {
