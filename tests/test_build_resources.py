@@ -1,0 +1,49 @@
+"""CPU: the code object's per-kernel resource report (mv_ldm_amd/csrc/kernel_resources.json, written by the build from hipcc's
+kernel-resource-usage remarks).  Guards a failure no parity test sees: when hipcc stops promoting an accumulator array to
+registers it lands in per-lane scratch, results stay right and the kernel gets 3-4x slower (this round: the per-element
+fallback epilogue demoted the 64 x 64 wave tile's `acc` of tiles 1, 6, 7, 8 -- 320 bytes of scratch per lane)."""
+import json
+import re
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def resources():
+    from mv_ldm_amd import _build
+    _build.build()
+    if not _build.RES.exists():        # objects from a build that predates the report: recompile once
+        _build.build(force=True)
+    return json.loads(_build.RES.read_text())
+
+
+def test_report_covers_every_kernel_family(resources):
+    names = " ".join(resources)
+    for fam in ("igemm_bl_kernel", "igemm_halo_kernel", "igemm_kernel", "linear_pp_kernel", "attention_kernel", "attention_bwd",
+                "wgrad_kernel", "gn_", "layernorm", "adamw"):
+        assert fam in names, fam
+    assert all("vgpr" in v and "scratch" in v for v in resources.values())
+
+
+def test_hot_kernels_use_no_scratch(resources):
+    """16-bit implicit-GEMM kernels (every conv / Linear of the sampling path), the persistent Linear, the halo conv: zero
+    scratch, zero spills.  Known exceptions, listed so that a NEW one fails: the dual-source (skip-concat) 3x3 variants of the
+    three largest tiles, which spill ~30 registers / keep a tap table.  Forward attention is compiled to an occupancy target
+    (4 / 3 / 2 waves per SIMD by head dim) and spills a few registers outside the K/V loop's critical path: bounded here."""
+    hot = re.compile(r"igemm_bl_kernelIDF16[b_]|igemm_halo_kernelIDF16[b_]|linear_pp_kernel")
+    known = re.compile(r"igemm_bl_kernelIDF16[b_]Li(128ELi256ELi2ELi4|256ELi256ELi4ELi2|256ELi320ELi4ELi2)ELi3ELb1E")
+    bad = {k: (v["scratch"], v.get("vgpr_spill", 0)) for k, v in resources.items()
+           if hot.search(k) and not known.search(k) and (v["scratch"] or v.get("vgpr_spill", 0))}
+    assert not bad, bad
+    assert sum(1 for k in resources if hot.search(k)) >= 60
+    attn = {k: v for k, v in resources.items() if "16attention_kernel" in k}
+    assert attn and all(v["scratch"] <= 128 for v in attn.values()), {k: v["scratch"] for k, v in attn.items() if v["scratch"] > 128}
+
+
+def test_register_budgets(resources):
+    """8-wave kernels (512 threads, 2 waves per SIMD) must fit 256 registers; the persistent Linear keeps its two accumulator
+    sets (128) + fragments + epilogue state under that"""
+    for k, v in resources.items():
+        assert v["vgpr"] + v.get("agpr", 0) <= 512, k
+        if "linear_pp_kernel" in k:
+            assert v["vgpr"] <= 224 and v["waves_per_simd"] >= 2, (k, v)
