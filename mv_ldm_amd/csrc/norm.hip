@@ -318,6 +318,74 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Narrow rows (the UNet's 320 / 640 / 1280 channels = 40 / 80 / 160 16-byte chunks): one wave per row leaves 24 of 64 lanes idle
+// at c = 320 and keeps a single 16-byte load per lane in flight (3.7 TB/s).  Here a wave takes 64 / LPR rows at once, LPR lanes
+// per row with CPL chunks each (chunk index = lane-in-row + k * LPR: every load instruction covers whole 128-byte lines), all
+// CPL loads of a lane in flight together; gamma / beta stay in registers over the rows a wave walks.  Same two-pass statistics.
+template <typename T, int LPR, int CPL>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int rows, int c, float eps) {
+    constexpr int EPC = Elt<T>::EPC, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane & (LPR - 1), rsel = lane / LPR;
+    float g[CPL][EPC], b[CPL][EPC];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) {
+            g[k][i] = gamma[(sub + k * LPR) * EPC + i];
+            b[k][i] = beta[(sub + k * LPR) * EPC + i];
+        }
+    const float inv_c = 1.0f / (float)c;
+    const int stride = gridDim.x * 4 * RPW;
+    for (int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW; row0 < rows; row0 += stride) {
+        const int row = row0 + rsel;
+        const bool ok = row < rows;
+        const T* xr = x + (size_t)(ok ? row : 0) * c;
+        Chunk<T> v[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) v[k] = load_chunk<T>(xr + (sub + k * LPR) * EPC);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) s += v[k].get(i);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) {
+                const float d = v[k].get(i) - mean;
+                q += d * d;
+            }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q * inv_c + eps);
+        if (!ok) continue;
+        T* yr = y + (size_t)row * c;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            Chunk<T> o;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) o.set(i, (v[k].get(i) - mean) * rstd * g[k][i] + b[k][i]);
+            store_chunk<T>(yr + (sub + k * LPR) * EPC, o);
+        }
+    }
+}
+
+template <typename T, int CPL>
+static bool layernorm_rows_launch(const T* x, T* y, const float* gamma, const float* beta, int rows, int c, float eps, int lpr, hipStream_t s) {
+    const int rpw = 64 / lpr;
+    const int blocks = std::min((rows + 4 * rpw - 1) / (4 * rpw), 256 * 16);
+    if (lpr == 8) hipLaunchKernelGGL((layernorm_rows_kernel<T, 8, CPL>), dim3(blocks), dim3(256), 0, s, x, y, gamma, beta, rows, c, eps);
+    else if (lpr == 16) hipLaunchKernelGGL((layernorm_rows_kernel<T, 16, CPL>), dim3(blocks), dim3(256), 0, s, x, y, gamma, beta, rows, c, eps);
+    else if (lpr == 32) hipLaunchKernelGGL((layernorm_rows_kernel<T, 32, CPL>), dim3(blocks), dim3(256), 0, s, x, y, gamma, beta, rows, c, eps);
+    else return false;
+    return true;
+}
+
 int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, const float* beta, int n_img, int hw, int c0,
                   int c1, int groups, float eps, int silu, int dtype, void* stats_ws, float* stats_out, hipStream_t s) {
     MVLDM_REQUIRE(groups > 0 && groups <= 64 && (c0 + c1) % groups == 0, "groupnorm: c=%d groups=%d", c0 + c1, groups);
@@ -381,6 +449,20 @@ int layernorm_run(const void* x, void* y, const float* gamma, const float* beta,
         using T = decltype(t);
         const T* xp = reinterpret_cast<const T*>(x);
         T* yp = reinterpret_cast<T*>(y);
+        if constexpr (sizeof(T) == 2) {
+            // chunks = LPR * CPL with LPR in {8, 16, 32} lanes per row and CPL in {3, 4, 5} chunks per lane, many rows
+            if (rows >= 1024) {
+                for (int cpl = 5; cpl >= 3; --cpl) {
+                    if (ncc % cpl) continue;
+                    const int lpr = ncc / cpl;
+                    if (lpr != 8 && lpr != 16 && lpr != 32) continue;
+                    const bool ok = cpl == 5 ? layernorm_rows_launch<T, 5>(xp, yp, gamma, beta, rows, c, eps, lpr, s)
+                                  : cpl == 4 ? layernorm_rows_launch<T, 4>(xp, yp, gamma, beta, rows, c, eps, lpr, s)
+                                             : layernorm_rows_launch<T, 3>(xp, yp, gamma, beta, rows, c, eps, lpr, s);
+                    if (ok) return check_launch();
+                }
+            }
+        }
         if (ncc <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);
         else if (ncc <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);
         else if (ncc <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, rows, c, eps);

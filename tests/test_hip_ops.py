@@ -269,8 +269,10 @@ def test_groupnorm(ops, dtype, n, c, h, w, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("rows,c", [(7, 64), (1024, 320), (80, 1280), (33, 2560)])
+@pytest.mark.parametrize("rows,c", [(7, 64), (1024, 320), (80, 1280), (33, 2560), (4099, 320), (2050, 640), (1027, 1280), (1500, 1024),
+                                    (1300, 384), (1111, 192), (70000, 320)])
 def test_layernorm(ops, dtype, rows, c):
+    # (>= 1024 rows of 8/16/32 x {3,4,5} chunks: the multi-row kernel, ragged last row group; else one wave per row)
     x = (rnd((rows, c), 29, dtype) * 1.5 + 0.3).to(dtype).float()
     gm, bt = 1 + 0.2 * torch.randn(c, generator=G(30)), 0.2 * torch.randn(c, generator=G(31))
     y = ops.layernorm(x.to(dtype).cuda(), gm.cuda(), bt.cuda(), 1e-5)
