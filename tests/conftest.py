@@ -30,6 +30,15 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _grad_mode(request):
+    """autograd mode is per test MODULE, never a process-wide side effect of importing a test file.  Default off (forward-only
+    suites would otherwise keep graphs of billion-parameter models alive); the backward / training suites, which differentiate
+    torch references, say `GRAD_ENABLED = True` at module level"""
+    with torch.set_grad_enabled(getattr(request.module, "GRAD_ENABLED", False)):
+        yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

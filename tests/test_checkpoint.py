@@ -10,7 +10,7 @@ from mv_ldm_amd.pipeline import MVLDMPipeline, SamplerCfg
 from mv_ldm_amd.scheduler import DDIMScheduler
 from mv_ldm_amd.vae import AutoencoderKL
 
-torch.set_grad_enabled(False)
+GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
 WIDTHS = (64, 64, 128, 128)
 
 

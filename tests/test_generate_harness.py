@@ -9,6 +9,8 @@ import torch
 
 from mv_ldm_amd import generate as G
 
+GRAD_ENABLED = False      # tests/conftest.py::_grad_mode
+
 SMALL = {"denoiser": dict(block_out_channels=(64, 64, 128, 128), attention_head_dim=(1, 1, 2, 2)),
          "autoencoder": dict(block_out_channels=(32, 32, 64, 64))}
 
@@ -83,7 +85,6 @@ def test_harness_end_to_end_and_rank_sharding(mode, tmp_path):
     scenes are independent and, with a seed, every (scene, call) owns its noise stream"""
     import mv_ldm_amd
     from mv_ldm_amd.image_io import decode_png
-    torch.set_grad_enabled(False)
     cfg = _small_cfg(sampling_mode=mode, limit_frames=13)
     pipe, _ = G.build_pipeline(cfg, device="cuda", allow_random_init=True, overrides=SMALL)
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -118,7 +119,6 @@ def test_harness_end_to_end_and_rank_sharding(mode, tmp_path):
 @pytest.mark.gpu
 def test_cli_runs_the_released_topology(capsys):
     """`python -m mv_ldm_amd.generate` on the full-width model (random init), 2 scenes, 13 frames, 2 DDIM steps"""
-    torch.set_grad_enabled(False)
     rc = G.main(["model.scheduler.num_inference_steps=2", "test.limit_frames=13", "seed=1", "--scenes", "2", "--frames", "13",
                  "--res", "256", "--dtype", "bf16", "--allow-random-init"])
     assert rc == 0

@@ -9,6 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+GRAD_ENABLED = True       # tests/conftest.py::_grad_mode: torch references are differentiated here
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 1.2e-2}

@@ -22,7 +22,7 @@ from conftest import rel_err
 from seeded import random_cameras, seeded_state
 
 pytestmark = pytest.mark.gpu
-torch.set_grad_enabled(False)
+GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
 
 STEP_TOL = {torch.float32: 1e-3, torch.float16: 1e-2, torch.bfloat16: 3e-2}
 # 50 DDIM steps, CFG 3.0, random-init weights: the end-to-end drift of the 16-bit paths against the f32 HIP path.

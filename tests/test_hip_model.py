@@ -21,7 +21,7 @@ TOL_BLOCK = {torch.float32: 2e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}
 TOL_MODEL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 IDS = ["f32", "bf16", "f16"]
-torch.set_grad_enabled(False)
+GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
 
 
 @pytest.fixture(scope="module")

@@ -15,7 +15,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-torch.set_grad_enabled(False)
+GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
 
 
 @pytest.fixture(scope="module")

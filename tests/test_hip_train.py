@@ -12,6 +12,7 @@ import torch
 from seeded import load_seeded
 from test_oracle_train import build_oracle, g9_case
 
+GRAD_ENABLED = True       # tests/conftest.py::_grad_mode: torch references are differentiated here
 pytestmark = pytest.mark.gpu
 
 

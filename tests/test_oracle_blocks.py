@@ -12,7 +12,7 @@ from seeded import load_seeded
 from oracle import blocks as B
 from oracle.vae import AutoencoderKL
 
-torch.set_grad_enabled(False)
+GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
 G = lambda s: torch.Generator().manual_seed(s)
 
 

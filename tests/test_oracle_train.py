@@ -6,6 +6,8 @@ import torch
 
 from seeded import load_seeded
 
+GRAD_ENABLED = True       # tests/conftest.py::_grad_mode: torch references are differentiated here
+
 
 def build_oracle(g):
     from oracle import multiview as OMV
