@@ -251,18 +251,19 @@ int mvldm_igemm_wgrad(const mvldm_wgrad_desc* d, mvldm_stream_t stream);
 
 /* Column sums of a [n_seg * rows_per_seg][ld] activation matrix, columns [0, n): bias gradients (per_seg = 0:
  * dst[n] (+)= sum over all rows) and the gradient of the per-image time-embedding row added by ResnetBlock2D
- * (per_seg = 1: dst[seg][n] (ld_dst) (+)= sum over the rows of image seg).  workspace: fp32, >= n_seg * 64 * n floats. */
+ * (per_seg = 1: dst[seg][n] (ld_dst) (+)= sum over the rows of image seg).  workspace: fp32, 16-byte aligned,
+ * >= (1024 + n_seg) * roundup(n, 8) floats. */
 int mvldm_colsum(const void* x, float* dst, float* workspace, size_t workspace_bytes, int n_seg, int rows_per_seg, int n,
                  int ld, int ld_dst, int per_seg, int accumulate, int dtype, mvldm_stream_t stream);
 
 /* GroupNorm(+SiLU) backward (NHWC, optional two-source concat input as in the forward): dx0 / dx1 written,
  * dgamma / dbeta ACCUMULATED (+=).  stats: the forward's stats_out.  workspace: fp32,
- * >= n_img * MVLDM_GN_MAX_CHUNKS * (c0+c1) * 2 floats. */
+ * >= n_img * (MVLDM_GN_MAX_CHUNKS * (c0+c1) + groups) * 2 floats, 16-byte aligned. */
 int mvldm_groupnorm_bwd(const void* x0, const void* x1, const void* dy, void* dx0, void* dx1, const float* gamma,
                         const float* beta, const float* stats, float* dgamma, float* dbeta, int n_img, int hw, int c0,
                         int c1, int groups, int silu, int dtype, float* workspace, size_t workspace_bytes,
                         mvldm_stream_t stream);
-/* LayerNorm backward over [rows][c]: dx written, dgamma / dbeta accumulated.  workspace: fp32, >= 512 * c * 2 floats. */
+/* LayerNorm backward over [rows][c]: dx written, dgamma / dbeta accumulated.  workspace: fp32, >= 512 * c * 2 floats, 16-byte aligned. */
 int mvldm_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma, float* dbeta,
                         int rows, int c, float eps, int dtype, float* workspace, size_t workspace_bytes,
                         mvldm_stream_t stream);

@@ -3,10 +3,11 @@
 // GroupNorm: y = act(z * gamma + beta), z = (x - mean_g) * rstd_g over (pixels, channels of the group) of one image,
 // act = SiLU or identity.  With dg = dy * act'(z gamma + beta), dz = dg * gamma:
 //     dgamma[c] = sum dg * z      dbeta[c] = sum dg      dx = rstd * (dz - mean_g(dz) - z * mean_g(dz * z))
-// Three launches: (1) per (image, row slab): per-channel partial sums of dg and dg*z (a thread owns one 16-byte channel
-// column, fixed order, no atomics to HBM); (2) per (image, row slab): fold the partials into the two group means and
-// write dx (x and dy are read a second time: L2/MALL-resident at these sizes); (3) per channel: fold the partials over
-// images and slabs into dgamma / dbeta (accumulating: parameters may collect several micro-batches).
+// Four launches: (1) per (image, row slab): per-channel partial sums of dg and dg*z (a thread owns one 16-byte channel
+// column, fixed order, no atomics to HBM); (2) per (image, group): fold the image's partials into the two group means (once --
+// the first version re-folded them in every one of the 512-1024 slab workgroups of step 3); (3) per (image, row slab): write
+// dx (x and dy are read a second time: L2/MALL-resident at these sizes); (4) fold the partials over images and slabs into
+// dgamma / dbeta (reduce.h; accumulating: parameters may collect several micro-batches).
 // (mean, rstd) come from the forward pass (`stats_out` of mvldm_groupnorm_fwd).  The input may be the channel concat of
 // two tensors (the up-path skip concat): dx is then written as two tensors.
 //
@@ -15,6 +16,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "reduce.h"
 
 namespace mvldm {
 
@@ -81,37 +83,39 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const T* __restrict
     }
 }
 
+// means[img][g] = (mean_g(dz), mean_g(dz * z)), dz = dg * gamma: one wave per (image, group), fixed order
+__global__ __launch_bounds__(256) void gn_bwd_means_kernel(const float* __restrict__ part, const float* __restrict__ gamma, float* __restrict__ means,
+                                                           int n_img, int hw, int c, int groups, int nchunk) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= n_img * groups) return;
+    const int img = idx / groups, g = idx - img * groups, cpg = c / groups;
+    float t1 = 0.f, t2 = 0.f;
+    for (int e = lane; e < cpg * nchunk; e += 64) {
+        const int k = e / cpg, ch = g * cpg + (e - k * cpg);
+        const float* pp = part + (((size_t)img * nchunk + k) * c + ch) * 2;
+        t1 += pp[0] * gamma[ch];
+        t2 += pp[1] * gamma[ch];
+    }
+    t1 = wave_sum(t1);
+    t2 = wave_sum(t2);
+    if (lane == 0) {
+        const float inv = 1.0f / ((float)hw * (float)cpg);
+        means[(size_t)idx * 2] = t1 * inv;
+        means[(size_t)idx * 2 + 1] = t2 * inv;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int c0, const T* __restrict__ dy,
                                                            T* __restrict__ dx0, T* __restrict__ dx1, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ stats,
-                                                           const float* __restrict__ part, int hw, int c, int groups, int rows_per_chunk,
+                                                           const float* __restrict__ means, int hw, int c, int groups, int rows_per_chunk,
                                                            int nchunk, int silu) {
     constexpr int EPC = Elt<T>::EPC;
-    __shared__ float s_m1[64], s_m2[64];      // group means of dz and dz*z
     const int img = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
     const int ncc = c / EPC, cpg = c / groups;
-    if (threadIdx.x < 64) { s_m1[threadIdx.x] = 0.f; s_m2[threadIdx.x] = 0.f; }
-    __syncthreads();
-    // fold this image's partials: one wave per group at a time, fixed order
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int g = wave; g < groups; g += 4) {
-        float t1 = 0.f, t2 = 0.f;
-        for (int e = lane; e < cpg * nchunk; e += 64) {
-            const int k = e / cpg, ch = g * cpg + (e - k * cpg);
-            const float* pp = part + (((size_t)img * nchunk + k) * c + ch) * 2;
-            t1 += pp[0] * gamma[ch];
-            t2 += pp[1] * gamma[ch];
-        }
-        t1 = wave_sum(t1);
-        t2 = wave_sum(t2);
-        if (lane == 0) {
-            const float inv = 1.0f / ((float)hw * (float)cpg);
-            s_m1[g] = t1 * inv;
-            s_m2[g] = t2 * inv;
-        }
-    }
-    __syncthreads();
+    const float* mimg = means + (size_t)img * groups * 2;
     const int r0 = chunk * rows_per_chunk, r1 = min(hw, r0 + rows_per_chunk);
     for (int cc0 = 0; cc0 < ncc; cc0 += 256) {
         const int span = min(ncc - cc0, 256);
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             rs[i] = stats[((size_t)img * groups + g) * 2 + 1];
             ga[i] = gamma[ch0 + i];
             be[i] = beta[ch0 + i];
-            m1[i] = s_m1[g];
-            m2[i] = s_m2[g];
+            m1[i] = mimg[2 * g];
+            m2[i] = mimg[2 * g + 1];
         }
         for (int r = r0 + rl; r < r1; r += RB) {
             const Chunk<T> xv = load_chunk<T>(xs + (size_t)r * cs), dv = load_chunk<T>(ds + (size_t)r * c);
@@ -151,21 +155,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             store_chunk<T>(dst + (size_t)r * cs, o);
         }
     }
-}
-
-// dgamma[ch] += sum over (image, slab) of part[..][ch][1];  dbeta[ch] += ...[0]
-__global__ __launch_bounds__(256) void norm_param_grad_kernel(const float* __restrict__ part, int n_part, int c, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= c) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < n_part; ++k) {
-        const float* pp = part + ((size_t)k * c + ch) * 2;
-        a += pp[0];
-        b += pp[1];
-    }
-    dbeta[ch] += a;
-    dgamma[ch] += b;
 }
 
 // ---------------------------------------------------------------------------------------------- LN
@@ -276,8 +265,10 @@ int groupnorm_bwd_run(const void* x0, const void* x1, const void* dy, void* dx0,
     MVLDM_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0 && c0 % epc == 0 && c1 % epc == 0, "groupnorm_bwd: c=(%d,%d) groups=%d", c0, c1, groups);
     int nchunk, rpc;
     gn_chunks(n_img, hw, nchunk, rpc);
-    MVLDM_REQUIRE((size_t)n_img * nchunk * c * 2 * sizeof(float) <= ws_bytes, "groupnorm_bwd: workspace too small (need %zu bytes)",
-                  (size_t)n_img * nchunk * c * 2 * sizeof(float));
+    const size_t n_part = (size_t)n_img * nchunk * c * 2;       // floats; the group means follow them
+    MVLDM_REQUIRE((n_part + (size_t)n_img * groups * 2) * sizeof(float) <= ws_bytes && ((uintptr_t)ws % 16) == 0,
+                  "groupnorm_bwd: workspace too small or not 16-byte aligned (need %zu bytes)", (n_part + (size_t)n_img * groups * 2) * sizeof(float));
+    float* means = ws + n_part;
     const int span = std::min(c / epc, 256), rb = std::max(1, 256 / span);
     const size_t smem = (size_t)rb * span * epc * 2 * sizeof(float);
     return dispatch_dtype(dtype, [&](auto t) {
@@ -286,12 +277,15 @@ int groupnorm_bwd_run(const void* x0, const void* x1, const void* dy, void* dx0,
                            reinterpret_cast<const T*>(x1), c0, reinterpret_cast<const T*>(dy), gamma, beta, stats, ws, hw, c, groups, rpc, nchunk, silu);
         int rc = check_launch();
         if (rc) return rc;
+        hipLaunchKernelGGL(gn_bwd_means_kernel, dim3((n_img * groups + 3) / 4), dim3(256), 0, s, ws, gamma, means, n_img, hw, c, groups, nchunk);
+        rc = check_launch();
+        if (rc) return rc;
         hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(n_img * nchunk), dim3(256), 0, s, reinterpret_cast<const T*>(x0), reinterpret_cast<const T*>(x1),
-                           c0, reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx0), reinterpret_cast<T*>(dx1), gamma, beta, stats, ws, hw, c,
+                           c0, reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx0), reinterpret_cast<T*>(dx1), gamma, beta, stats, means, hw, c,
                            groups, rpc, nchunk, silu);
         rc = check_launch();
         if (rc) return rc;
-        hipLaunchKernelGGL(norm_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws, n_img * nchunk, c, dgamma, dbeta);
+        hipLaunchKernelGGL(fold_partials_kernel<1>, dim3(c * 2 / 4, 1), dim3(256), 0, s, ws, n_img * nchunk, c * 2, c * 2, dbeta, dgamma, 0, 1);
         return check_launch();
     });
 }
@@ -303,8 +297,8 @@ int layernorm_bwd_run(const void* x, const void* dy, void* dx, const float* gamm
     MVLDM_REQUIRE(x && dy && dx && gamma && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
     MVLDM_REQUIRE(c % epc == 0 && c / epc <= 64 * 8, "layernorm_bwd: c=%d", c);
     const int blocks = std::max(1, std::min((rows + 3) / 4, 512));
-    MVLDM_REQUIRE((size_t)blocks * c * 2 * sizeof(float) <= ws_bytes, "layernorm_bwd: workspace too small (need %zu bytes)",
-                  (size_t)blocks * c * 2 * sizeof(float));
+    MVLDM_REQUIRE((size_t)blocks * c * 2 * sizeof(float) <= ws_bytes && ((uintptr_t)ws % 16) == 0,
+                  "layernorm_bwd: workspace too small or not 16-byte aligned (need %zu bytes)", (size_t)blocks * c * 2 * sizeof(float));
     const size_t smem = (size_t)4 * c * 2 * sizeof(float);
     const int ncc = c / epc;
     return dispatch_dtype(dtype, [&](auto t) {
@@ -323,7 +317,7 @@ int layernorm_bwd_run(const void* x, const void* dy, void* dx, const float* gamm
 #undef MVLDM_LN_BWD
         int rc = check_launch();
         if (rc) return rc;
-        hipLaunchKernelGGL(norm_param_grad_kernel, dim3((c + 255) / 256), dim3(256), 0, s, ws, blocks, c, dgamma, dbeta);
+        hipLaunchKernelGGL(fold_partials_kernel<1>, dim3(c * 2 / 4, 1), dim3(256), 0, s, ws, blocks, c * 2, c * 2, dbeta, dgamma, 0, 1);
         return check_launch();
     });
 }

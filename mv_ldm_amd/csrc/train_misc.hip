@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "reduce.h"
 
 namespace mvldm {
 
@@ -55,21 +56,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
         __syncthreads();
     }
 }
-// dst[seg][n] (ld_dst) = / += sum over chunks (per_seg), or dst[n] += sum over segments and chunks (!per_seg)
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ dst, int n_seg,
-                                                            int nchunk, int n, int n_valid, int ld_dst, int per_seg, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int total = per_seg ? n_seg * n_valid : n_valid;
-    if (idx >= total) return;
-    const int seg = per_seg ? idx / n_valid : 0, col = per_seg ? idx - seg * n_valid : idx;
-    float t = 0.f;
-    const int s0 = per_seg ? seg : 0, s1 = per_seg ? seg + 1 : n_seg;
-    for (int sg = s0; sg < s1; ++sg)
-        for (int k = 0; k < nchunk; ++k) t += part[((size_t)sg * nchunk + k) * n + col];
-    float* o = dst + (size_t)seg * ld_dst + col;
-    *o = accumulate ? *o + t : t;
-}
-
 // ---- elementwise forward/backward --------------------------------------------------------------------
 enum { TE_SILU_BWD = 0, TE_ADD = 1, TE_GEGLU_FWD = 2, TE_GEGLU_BWD = 3, TE_GELU_BWD = 4 };
 
@@ -296,11 +282,12 @@ int colsum_run(const void* x, float* dst, float* ws, size_t ws_bytes, int n_seg,
     const int n_valid = n;
     n = (n + epc - 1) / epc * epc;
     MVLDM_REQUIRE(ld % epc == 0 && ld >= n, "colsum: n=%d ld=%d (ld must be a multiple of %d and cover the padded width)", n_valid, ld, epc);
-    int nchunk = std::max(1, std::min(std::min(rows_per_seg / 16, 64), (2048 + n_seg - 1) / n_seg));
+    // about 1024 first-stage workgroups in total (the second stage folds any number of partial rows in parallel: reduce.h)
+    int nchunk = std::max(1, std::min(std::min(rows_per_seg / 8, 512), (1024 + n_seg - 1) / n_seg));
     const int rpc = (rows_per_seg + nchunk - 1) / nchunk;
     nchunk = (rows_per_seg + rpc - 1) / rpc;
-    MVLDM_REQUIRE((size_t)n_seg * nchunk * n * sizeof(float) <= ws_bytes, "colsum: workspace of %zu bytes too small (need %zu)", ws_bytes,
-                  (size_t)n_seg * nchunk * n * sizeof(float));
+    MVLDM_REQUIRE((size_t)n_seg * nchunk * n * sizeof(float) <= ws_bytes && ((uintptr_t)ws % 16) == 0,
+                  "colsum: workspace of %zu bytes too small (need %zu) or not 16-byte aligned", ws_bytes, (size_t)n_seg * nchunk * n * sizeof(float));
     const int span = std::min(n / epc, 256), rb = std::max(1, 256 / span);
     const size_t smem = (size_t)rb * span * epc * sizeof(float);
     int rc = dispatch_dtype(dtype, [&](auto t) {
@@ -309,8 +296,9 @@ int colsum_run(const void* x, float* dst, float* ws, size_t ws_bytes, int n_seg,
         return check_launch();
     });
     if (rc) return rc;
-    const int total = per_seg ? n_seg * n_valid : n_valid;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, s, ws, dst, n_seg, nchunk, n, n_valid, ld_dst, per_seg, accumulate);
+    // dst[seg][n] (ld_dst) = / += sum over the segment's chunks (per_seg), or dst[n] = / += sum over all segments and chunks
+    if (per_seg) hipLaunchKernelGGL(fold_partials_kernel<0>, dim3(n / 4, n_seg), dim3(256), 0, s, ws, nchunk, n, n_valid, dst, nullptr, ld_dst, accumulate);
+    else hipLaunchKernelGGL(fold_partials_kernel<0>, dim3(n / 4, 1), dim3(256), 0, s, ws, n_seg * nchunk, n, n_valid, dst, nullptr, 0, accumulate);
     return check_launch();
 }
 

@@ -381,7 +381,7 @@ def colsum(x2d, dst, rows_per_seg=None, per_seg=False, accumulate=False, n=None)
     n = x2d.shape[1] if n is None else n
     rows_per_seg = rows if rows_per_seg is None else rows_per_seg
     n_seg = rows // rows_per_seg
-    ws = workspace(max(n_seg * 64 * n * 4, 1 << 16), x2d.device, "colsum")
+    ws = workspace(max((1024 + n_seg) * ((n + 7) // 8 * 8) * 4, 1 << 16), x2d.device, "colsum")
     L.check(L.load().mvldm_colsum(x2d.data_ptr(), dst.data_ptr(), ws.data_ptr(), ws.numel(), n_seg, rows_per_seg, n, x2d.stride(0),
                                   dst.stride(0) if dst.ndim == 2 else n, int(per_seg), int(accumulate), dt(x2d), stream()))
     return dst
@@ -392,7 +392,7 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, dgamma, dbeta, groups, silu, x2=Non
     c1 = 0 if x2 is None else x2.shape[-1]
     hw = math.prod(x.shape[1:-1])
     dx, dx2 = torch.empty_like(x), (None if x2 is None else torch.empty_like(x2))
-    ws = workspace(n * L.GN_MAX_CHUNKS * (c0 + c1) * 2 * 4, x.device, "gnb")
+    ws = workspace(n * (L.GN_MAX_CHUNKS * (c0 + c1) + groups) * 2 * 4, x.device, "gnb")
     L.check(L.load().mvldm_groupnorm_bwd(x.data_ptr(), ptr(x2), dy.data_ptr(), dx.data_ptr(), ptr(dx2), gamma.data_ptr(), beta.data_ptr(),
                                          stats.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), n, hw, c0, c1, groups, int(silu), dt(x),
                                          ws.data_ptr(), ws.numel(), stream()))
