@@ -1,0 +1,52 @@
+"""where one optimizer step of the training path spends its wall time (configs[3] shape): prepare (VAE encode + input staging),
+weight re-pack after an optimizer step, the forward+backward plan, the optimizer step.  python tools/train_timeline.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import mv_ldm_amd
+from mv_ldm_amd import _lib
+from mv_ldm_amd.mvunet import MultiViewUNet, MultiViewUNetCfg
+from mv_ldm_amd.scheduler import DDIMScheduler
+from mv_ldm_amd.train import MVLDMTrainer
+from mv_ldm_amd.vae import AutoencoderKL
+
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+_lib.load()
+mv_ldm_amd.set_compute_dtype(torch.bfloat16)
+with torch.device(dev):
+    den = MultiViewUNet(MultiViewUNetCfg(pretrained_from="stabilityai/stable-diffusion-2-1", allow_random_init=True), 11, 4)
+    vae = AutoencoderKL.from_pretrained("stabilityai/stable-diffusion-2-1", allow_random_init=True)
+bench.random_init_(den, 1234)
+bench.random_init_(vae, 1235)
+tr = MVLDMTrainer(den, vae, DDIMScheduler(clip_sample=False), dtype=torch.bfloat16)
+b = 4
+batch = bench.synthetic_batch(b, 1, 3, 256, 4000, dev)
+batch["target"]["image"] = torch.rand(b, 3, 3, 256, 256).to(dev)
+for _ in range(4):
+    tr.training_step(batch, index=1, unconditional=False)
+torch.cuda.synchronize()
+
+def timed(f):
+    torch.cuda.synchronize(); t = time.perf_counter(); r = f(); torch.cuda.synchronize(); return r, 1e3 * (time.perf_counter() - t)
+
+acc = {}
+for it in range(3):
+    for micro in range(2):
+        if micro == 0:
+            _, t = timed(lambda: (tr.flat.zero_grad(), [p.loss.zero_() for p in tr.plans.values()]))
+            acc["zero_grad"] = acc.get("zero_grad", 0) + t
+        tp, t = timed(lambda: tr.prepare(batch, index=1, unconditional=False))
+        acc["prepare (VAE encode + staging)"] = acc.get("prepare (VAE encode + staging)", 0) + t
+        if tr._stale:
+            _, t = timed(lambda: [p.refresh_weights() for p in tr.plans.values()])
+            acc["refresh_weights (re-pack)"] = acc.get("refresh_weights (re-pack)", 0) + t
+            tr._stale = False
+        _, t = timed(tp.run)
+        acc["plan (fwd + loss + bwd)"] = acc.get("plan (fwd + loss + bwd)", 0) + t
+        tr.micro += 1
+    _, t = timed(tr.opt.step)
+    acc["optimizer step"] = acc.get("optimizer step", 0) + t
+    tr._stale = True
+print({k: round(v / 3, 2) for k, v in acc.items()}, "ms per optimizer step (2 micro-batches)")
