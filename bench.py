@@ -179,11 +179,7 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
         if args.op_table:
             with open(args.op_table, "w") as f:
                 json.dump([{"name": m.name, "kind": m.kind, "ms": t, "flops": m.flops, "bytes": m.bytes} for m, t in zip(tp.plan.meta, ms)], f, indent=0)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -200,6 +196,7 @@ def main():
     ap.add_argument("--op-table", default=None, help="write the per-op profile (JSON) here")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the b in {1, 4, 16} latency lines")
     ap.add_argument("--no-parity", action="store_true", help="skip the 50-step f32-vs-bench-dtype drift measurement")
+    ap.add_argument("--no-train-line", action="store_true", help="skip the short training-step measurement appended to the sampling line")
     ap.add_argument("--train", action="store_true",
                     help="measure the TRAINING step instead (BASELINE.json configs[3]): K optimizer steps of 2 micro-batches of "
                          "--scenes x 4 views, bf16, AdamW, clip 0.1; N > 1: ZeRO-1 reduce-scatter / all-gather over RCCL")
@@ -254,7 +251,13 @@ def main():
             torch.cuda.synchronize()
 
     if args.train:
-        return train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params)
+        out = train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     pipe = MVLDMPipeline(den, vae, DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, args.ddim_steps))
     pipe.set_timesteps(args.ddim_steps)
     b, v_c, v_t = args.scenes, 1, 4
@@ -425,6 +428,15 @@ def main():
         out["parity_rel_err"] = {f"{args.dtype}_vs_f32_latents_after_{args.ddim_steps}_steps": round(err, 5),
                                  "f32_vs_cpu_oracle_per_step": "<= 1e-3 (asserted by tests/test_hip_headline.py; measured ~1e-5)",
                                  "note": "seeded random-init weights, 1 scene, CFG 3.0; DDIM/CFG update and index work are bit-exact"}
+    if world == 1 and not args.no_train_line:
+        # ---- the training step of the same path (BASELINE configs[3]; `python bench.py --train` is the full-length run).  Last
+        # GPU work of the process: the fused AdamW updates the denoiser's weights in place.
+        import copy
+        targs = copy.copy(args)
+        targs.steps, targs.warmup, targs.op_table, targs.scenes = 3, 1, None, 64
+        t = train_bench(targs, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params)
+        out["training"] = {k: t[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "micro_batch_ms",
+                                              "micro_batch_tflops", "grad_norm") if k in t}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.res // 8)
     if rank == 0:
