@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -662,8 +663,10 @@ class TrainPlan:
     shape = (b scenes, v_c context views [0 = unconditional], v_t target views, hl, wl)."""
 
     def __init__(self, den, flat: FlatParams, b: int, v_c: int, v_t: int, hl: int, wl: int, dtype, loss_scale: float = 1.0,
-                 grad_scale: float = 1.0, graph: bool = False, rays=None):
+                 grad_scale: float = 1.0, graph: bool = False, rays=None, tune: Optional[bool] = None):
         dev = flat.flat.device
+        if tune is None:        # plan-time tile selection of the forward / data-gradient implicit GEMMs (MVLDM_TRAIN_AUTOTUNE=0: rules only)
+            tune = os.environ.get("MVLDM_TRAIN_AUTOTUNE", "1") != "0" and os.environ.get("MVLDM_AUTOTUNE", "1") != "0"
         self.shape = (b, v_c, v_t, hl, wl)
         v = v_c + v_t
         n_img, lc = b * v, den.out_channels
@@ -713,7 +716,7 @@ class TrainPlan:
         assert not bld.tape
         self.eps, self.unet_in, self.tgt_img = eps, unet_in, tgt_img
         self.touched, self.grad_writes, self.repack = bld.touched, bld.grad_writes, bld.repack
-        self.plan: Plan = bld.finalize(autotune=False)
+        self.plan: Plan = bld.finalize(autotune=tune)
         self.graph = graph
         if graph:       # (capturing runs the plan once eagerly: the caller restores the gradient / loss accumulators)
             self.plan.capture()
