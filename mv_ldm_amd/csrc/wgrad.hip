@@ -15,6 +15,7 @@
 // fp32 partial tile to a workspace slab and `wgrad_reduce_kernel` folds the slabs in a fixed order (deterministic, no
 // atomics) into the PyTorch-layout fp32 gradient ([n][c][ky][kx] / [n][c]), accumulating when asked to (micro-batches).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -216,7 +217,8 @@ int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits) {
     p.kdim = p.taps * p.ctot;
     const int tiles = p.tiles_n * p.taps * p.tiles_c;
     const int blocks = cdiv_(p.M, WG_BP);
-    splits = std::max(1, std::min(cdiv_(1024, tiles), std::max(1, blocks / 4)));
+    static const int kTarget = getenv("MVLDM_WGRAD_TARGET") ? atoi(getenv("MVLDM_WGRAD_TARGET")) : 512;   // workgroups aimed at (512 / 1024 / 2048 / 4096: 303 / 300 / 300 / 292 training views/s)
+    splits = std::max(1, std::min(cdiv_(kTarget, tiles), std::max(1, blocks / 4)));
     const size_t slab = (size_t)d.n_out * p.kdim * sizeof(float);
     while (splits > 1 && (size_t)splits * slab > d.workspace_bytes) --splits;
     MVLDM_REQUIRE(d.workspace && (size_t)splits * slab <= d.workspace_bytes, "wgrad: workspace of %zu bytes too small (need >= %zu)",
