@@ -433,7 +433,7 @@ def main():
         # GPU work of the process: the fused AdamW updates the denoiser's weights in place.
         import copy
         targs = copy.copy(args)
-        targs.steps, targs.warmup, targs.op_table, targs.scenes = 3, 1, None, 64
+        targs.steps, targs.warmup, targs.op_table, targs.scenes = 4, 2, None, 64
         t = train_bench(targs, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params)
         out["training"] = {k: t[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "micro_batch_ms",
                                               "micro_batch_tflops", "grad_norm") if k in t}
