@@ -14,6 +14,8 @@ template <int OP> __global__ __launch_bounds__(256) void k(float* out, int iters
             if (OP == 1) v[i] = __builtin_fmaf(v[i], 1.0001f, 0.5f);
             if (OP == 2) v[i] = __builtin_amdgcn_rcpf(v[i]);
             if (OP == 4) v[i] = __builtin_fmaxf(__builtin_fmaxf(v[i], v[(i + 1) & 15]), v[(i + 2) & 15]);
+            if (OP == 5) { _Float16 h = (_Float16)v[i]; asm volatile("v_exp_f16 %0, %1" : "=v"(h) : "v"(h)); v[i] = (float)h; }   // + 2 conversions
+            if (OP == 6) { _Float16 h = (_Float16)v[i]; asm volatile("v_mov_b32 %0, %1" : "=v"(h) : "v"(h)); v[i] = (float)h; }   // the conversions alone
         }
         if (OP == 3) {
 #pragma unroll
@@ -36,4 +38,5 @@ template <int OP> void run(const char* name, int per_iter) {
         printf("%-14s %4d blocks: %.3f ms -> %.2f ns per wave-instruction per SIMD (x clock GHz = cycles)\n", name, blocks, ms, ms * 1e6 / inst);
     }
 }
-int main() { run<1>("v_fma_f32", 16); run<0>("v_exp_f32", 16); run<2>("v_rcp_f32", 16); run<3>("v_pk_fma_f32", 8); run<4>("v_max3_f32", 16); return 0; }
+int main() { run<1>("v_fma_f32", 16); run<0>("v_exp_f32", 16); run<2>("v_rcp_f32", 16); run<3>("v_pk_fma_f32", 8); run<4>("v_max3_f32", 16);
+    run<5>("v_exp_f16+2cvt", 16); run<6>("v_mov+2cvt", 16); return 0; }
