@@ -233,6 +233,38 @@ def test_persistent_tile_refuses_what_it_cannot_do(ops):
         ops.linear(torch.randn(128, 256, device="cuda").to(torch.bfloat16), pw1, tile=12)     # K = 256: 4 K-tiles, the epilogue needs 5 steps
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_block_major_packers_bit_exact(ops, dtype):
+    """the LDS-tiled packers of the 16-bit block-major layout (forward 1x1 incl. GEGLU row interleave, forward 3x3, transposed
+    1x1 / 3x3 with a channel window) against the layout written out in torch: k = (64-channel block, tap, channel)"""
+    g = G(77)
+    # forward 3x3: n_out 70 (padded to 128), c_in 128
+    w = torch.randn(70, 128, 3, 3, generator=g)
+    pw = ops.pack_weight(w.cuda(), dtype)
+    assert pw.k_order == 1
+    ref = torch.zeros(pw.n_pad, 2, 9, 64)
+    ref[:70] = w.reshape(70, 2, 64, 9).permute(0, 1, 3, 2)
+    assert torch.equal(pw.data.float().cpu(), ref.reshape(pw.n_pad, -1).to(dtype).float())
+    # forward 1x1 with the GEGLU interleave: rows alternate [value 32 | gate 32]
+    wl = torch.randn(256, 192, generator=g)
+    pl = ops.pack_weight(wl.cuda(), dtype, geglu=True)
+    rows = torch.arange(256)
+    blk, wi = rows // 32, rows % 32
+    orig = torch.where(blk % 2 == 1, 128 + (blk // 2) * 32 + wi, (blk // 2) * 32 + wi)
+    assert torch.equal(pl.data.float().cpu(), wl[orig].to(dtype).float())
+    # transposed packs: rows = input channels [c_off, c_off + n_rows), K = (output block, flipped tap, output channel)
+    for wt, c_off, n_rows in ((torch.randn(128, 200, 3, 3, generator=g), 8, 150), (torch.randn(192, 96, generator=g), 0, 96)):
+        pt = ops.pack_weight_t(wt.cuda(), dtype, c_off, n_rows)
+        assert pt.k_order == 1
+        n_out = wt.shape[0]
+        taps = 9 if wt.ndim == 4 else 1
+        w4 = wt.reshape(n_out, wt.shape[1], taps)
+        ref = torch.zeros(pt.n_pad, n_out // 64, taps, 64)
+        src = w4[:, c_off:c_off + n_rows].flip(-1)                       # [n, r, tap']
+        ref[:n_rows] = src.permute(1, 0, 2).reshape(n_rows, n_out // 64, 64, taps).permute(0, 1, 3, 2)
+        assert torch.equal(pt.data.float().cpu(), ref.reshape(pt.n_pad, -1).to(dtype).float()), (wt.shape, c_off, n_rows)
+
+
 def test_pack_weight_layout(ops):
     w = torch.randn(70, 24, 3, 3, generator=G(24))
     pw = ops.pack_weight(w.cuda(), torch.float32)
