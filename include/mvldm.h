@@ -78,8 +78,8 @@ typedef struct mvldm_igemm_desc {
     int32_t dst_dtype;  /* act_dtype or MVLDM_F32 */
     int32_t splitk;     /* >= 1; 0 = let the library choose (needs workspace) */
     int32_t tile;       /* 0 = auto; else force a tile config (tests / tuning / plan-time selection): 1..11 igemm.hip tiles,
-                           12 = persistent Linear with the epilogue pipelined under the next tile (linear_pp.hip: 1x1, one source,
-                           K >= 320 a multiple of 64, 16-bit in and out; any other problem is an error, not a fallback) */
+                           12 = persistent Linear with the epilogue pipelined under the next tile (linear_pp.hip: 1x1, one or two
+                           sources, K >= 320 a multiple of 64, 16-bit in and out; any other problem is an error, not a fallback) */
     int32_t k_order;    /* K order of the packed weight: 0 = (tap, channel); 1 = (64-channel block, tap, channel) */
     int32_t dst_ld;     /* row stride of dst in elements; 0 = n_dst (dense).  > n_dst writes into a wider buffer */
     float out_scale;

@@ -1,5 +1,6 @@
 // Persistent, epilogue-pipelined Linear (1x1 conv over token rows) for the transformer blocks: tile 12 of the implicit-GEMM
-// family (include/mvldm.h: mvldm_igemm_fwd; 16-bit activations, one source, K a multiple of 64 and >= 320).
+// family (include/mvldm.h: mvldm_igemm_fwd; 16-bit activations, one source or the channel concat of two, K a multiple of 64
+// and >= 320).
 //
 // Why: the FF / QKV / projection GEMMs of the UNet have K = 320 ... 1280, i.e. 5-20 K-tiles per output tile.  In the general
 // kernel (igemm.hip) one workgroup owns the CU, so per output tile the ring fill latency, the main loop and the epilogue --
@@ -31,12 +32,12 @@
 namespace mvldm {
 
 struct LinPPParams {
-    const void* a; const void* w; const float* bias; const void* residual; void* dst;
-    int M, K, n_out, n_pad, n_dst, dst_ld, k_tiles;
+    const void* a; const void* a1; const void* w; const float* bias; const void* residual; void* dst;   // a1: second source of a channel concat (or NULL)
+    int M, K, c0, c1, kt0, n_out, n_pad, n_dst, dst_ld, k_tiles;    // K = c0 + c1; K-tiles [0, kt0) come from `a`, the rest from `a1`
     int tiles_m, tiles_n, m_per;       // m_per: 256-row blocks per XCD
     int cpt, nch;                      // a unit = up to `cpt` consecutive column tiles of one row block; nch units per row block
     float out_scale;
-    unsigned a_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
+    unsigned a_bytes, a1_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
 };
 
 // MVLDM_LPP_FAKE (roofline experiments of tools/fake_probe.sh only, compiled in only with -DMVLDM_EXPERIMENTS; results are
@@ -67,30 +68,38 @@ template <> struct LpMma<f16_t> {
 };
 
 // (buffer descriptors only in free functions: an opaque __amdgpu_buffer_rsrc_t inside a lambda trips hipcc's host pass)
-__device__ __forceinline__ void lp_issue(const LinPPParams& p, char* stage, int wave, int kt, const unsigned (&ao)[4], const unsigned (&bo)[2]) {
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, p.a_bytes, 0x00020000);
+__device__ __forceinline__ void lp_issue(const LinPPParams& p, char* stage, int wave, int kt, const unsigned (&ao)[2][4], const unsigned (&bo)[2]) {
+    // (skip-concat 1x1 convs: the K-tiles past kt0 read the second tensor -- its own descriptor, row pitch and K-tile origin)
+    const bool second = kt >= p.kt0;
+    // (ONE descriptor from selected scalars: a select between two descriptors becomes a branch, and hipcc then drains the ring
+    //  with vmcnt(0) at the join)
+    const void* abase = second ? p.a1 : p.a;
+    const unsigned abytes = second ? p.a1_bytes : p.a_bytes;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(abase), 0, abytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
-    const int soff = kt * 128;
+    const int soff_a = (second ? kt - p.kt0 : kt) * 128, soff_w = kt * 128;
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(stage + (wave + LP_NW * it) * 1024), 16, ao[it], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(stage + (wave + LP_NW * it) * 1024), 16,
+                                                 second ? ao[1][it] : ao[0][it], soff_a, 0, 0);
 #pragma unroll
     for (int it = 0; it < 2; ++it)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(stage + LP_BM * 128 + (wave + LP_NW * it) * 1024), 16,
-                                                 bo[it], soff, 0, 0);
+                                                 bo[it], soff_w, 0, 0);
 }
 
 // per-lane source offsets of this wave's DMA pieces for output tile (tm, tn): piece q covers tile rows 8q .. 8q+7, a lane
 // fetches the 16-byte chunk that belongs at its (linear) LDS position under the XOR swizzle.  valid == false: every piece
 // out of range (the ring keeps its cadence past the last tile: zeros into a slot nobody reads)
-__device__ __forceinline__ void lp_offsets(const LinPPParams& p, bool valid, int tm, int tn, int wave, int lane, unsigned (&ao)[4], unsigned (&bo)[2]) {
+__device__ __forceinline__ void lp_offsets(const LinPPParams& p, bool valid, int tm, int tn, int wave, int lane, unsigned (&ao)[2][4], unsigned (&bo)[2]) {
     const int slot = lane & 7, rsub = lane >> 3;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = (wave + LP_NW * it) * 8 + rsub;
         const int m = tm * LP_BM + row;
         const unsigned chunk = (unsigned)((slot ^ ((row >> 1) & 7)) * 8);
-        ao[it] = (valid && m < p.M) ? ((unsigned)m * (unsigned)p.K + chunk) * 2u : kLinOob;
+        ao[0][it] = (valid && m < p.M) ? ((unsigned)m * (unsigned)p.c0 + chunk) * 2u : kLinOob;
+        ao[1][it] = (valid && m < p.M) ? ((unsigned)m * (unsigned)p.c1 + chunk) * 2u : kLinOob;
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(512) void linear_pp_kernel(const LinPPParams p) {
             for (int r = 0; r < 16; ++r) accP[i][j][r] = 0.f;
 
     // ---- prologue: bias slab of the first tile, K-tiles 0 and 1 ----
-    unsigned ao[4], bo[2];
+    unsigned ao[2][4], bo[2];
     int kt_i = 1;                                // issue side: K-tile of the newest piece in flight
     {
         if (wave == 0) lp_issue_bias(p, smem, GEGLU, true, cur.tn, lane);
@@ -430,16 +439,16 @@ __global__ __launch_bounds__(512) void linear_pp_kernel(const LinPPParams p) {
 
 bool linear_pp_applicable(const mvldm_igemm_desc& d) {
     if (d.act_dtype == MVLDM_F32 || d.dst_dtype != d.act_dtype) return false;
-    if (d.ksize != 1 || d.stride != 1 || d.upsample != 0 || d.src1 || d.row_bias || d.k_order != 1 || d.splitk > 1) return false;
+    if (d.ksize != 1 || d.stride != 1 || d.upsample != 0 || d.row_bias || d.k_order != 1 || d.splitk > 1) return false;
     if (d.h_in != d.h_out || d.w_in != d.w_out || d.pad != 0) return false;
     if (d.epilogue != MVLDM_EPI_NONE && d.residual) return false;      // activation + residual: no caller, not instantiated
     const int n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
     const int dst_ld = d.dst_ld > 0 ? d.dst_ld : n_dst;
-    if (d.c0 % 64 || d.c0 < 320 || d.k_pad != d.c0 || d.n_out % 8 || n_dst % 8 || dst_ld % 8 || dst_ld < n_dst) return false;
+    if ((d.c1 == 0) != (d.src1 == nullptr) || d.c0 % 64 || d.c1 % 64 || d.c0 + d.c1 < 320 || d.k_pad != d.c0 + d.c1 || d.n_out % 8 || n_dst % 8 || dst_ld % 8 || dst_ld < n_dst) return false;
     if (d.epilogue == MVLDM_EPI_GEGLU && d.n_out % 64) return false;
     if (d.bias && ((uintptr_t)d.bias % 16)) return false;
     const double m = (double)d.n_img * d.h_out * d.w_out;
-    return m * d.c0 * 2.0 < 4.0e9 && (double)d.n_pad * d.k_pad * 2.0 < 4.0e9 && m * dst_ld * 2.0 < 4.0e9 && m * n_dst * 2.0 < 4.0e9;
+    return m * d.c0 * 2.0 < 4.0e9 && m * d.c1 * 2.0 < 4.0e9 && (double)d.n_pad * d.k_pad * 2.0 < 4.0e9 && m * dst_ld * 2.0 < 4.0e9 && m * n_dst * 2.0 < 4.0e9;
 }
 
 template <typename T, int EPI, bool RES> static int linear_pp_launch(const LinPPParams& p, int grid, hipStream_t s) {
@@ -455,18 +464,18 @@ template <typename T, int EPI, bool RES> static int linear_pp_launch(const LinPP
 int linear_pp_run(const mvldm_igemm_desc& d, hipStream_t s) {
     MVLDM_REQUIRE(linear_pp_applicable(d), "igemm: tile 12 (persistent pipelined Linear) does not apply to this problem");
     LinPPParams p;
-    p.a = d.src0; p.w = d.weight; p.bias = d.bias; p.residual = d.residual; p.dst = d.dst;
-    p.M = d.n_img * d.h_out * d.w_out; p.K = d.c0; p.n_out = d.n_out; p.n_pad = d.n_pad;
+    p.a = d.src0; p.a1 = d.src1; p.w = d.weight; p.bias = d.bias; p.residual = d.residual; p.dst = d.dst;
+    p.M = d.n_img * d.h_out * d.w_out; p.K = d.c0 + d.c1; p.c0 = d.c0; p.c1 = d.c1; p.kt0 = d.c0 / 64; p.n_out = d.n_out; p.n_pad = d.n_pad;
     p.n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
     p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
-    p.k_tiles = d.c0 / 64; p.out_scale = d.out_scale;
+    p.k_tiles = p.K / 64; p.out_scale = d.out_scale;
     p.tiles_m = (p.M + LP_BM - 1) / LP_BM; p.tiles_n = (d.n_pad + LP_BN - 1) / LP_BN;
     p.m_per = (p.tiles_m + 7) / 8;
-    p.a_bytes = (unsigned)((double)p.M * p.K * 2.0); p.w_bytes = (unsigned)((double)d.n_pad * d.k_pad * 2.0);
+    p.a_bytes = (unsigned)((double)p.M * p.c0 * 2.0); p.a1_bytes = (unsigned)((double)p.M * p.c1 * 2.0); p.w_bytes = (unsigned)((double)d.n_pad * d.k_pad * 2.0);
     p.bias_bytes = d.bias ? (unsigned)d.n_out * 4u : 0u;
     p.res_bytes = d.residual ? (unsigned)((double)p.M * p.n_dst * 2.0) : 0u;
     p.dst_bytes = (unsigned)((double)p.M * p.dst_ld * 2.0);
-    if (kLppFake & 1) p.a_bytes = 0;
+    if (kLppFake & 1) p.a_bytes = p.a1_bytes = 0;
     if (kLppFake & 2) p.w_bytes = 0;
     if (kLppFake & 4) p.dst_bytes = 0;
     static int n_cu = 0;

@@ -221,6 +221,22 @@ def test_geglu_persistent_tile(ops, dtype, rows, c):
     assert (y != y7).float().mean().item() < 0.05
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,h,c0,c1,cout", [(3, 16, 320, 320, 320), (5, 8, 640, 320, 640), (2, 32, 64, 576, 200)])
+def test_persistent_tile_two_sources(ops, dtype, n, h, c0, c1, cout):
+    """tile 12 on the 1x1 shortcut conv of an up-block resnet: the input is the channel concat of two tensors that is never
+    materialised -- K-tiles [0, c0/64) stream from the first, the rest from the second"""
+    x, x2 = rnd((n, c0, h, h), 51, dtype), rnd((n, c1, h, h), 52, dtype)
+    w = rnd((cout, c0 + c1), 53, dtype, 1 / math.sqrt(c0 + c1))
+    b = torch.randn(cout, generator=G(54)) * 0.1
+    pw = ops.pack_weight(w.cuda(), dtype, c_split=c0)
+    ref = F.conv2d(torch.cat([x, x2], 1).double(), w.double()[:, :, None, None], b.double())
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=nhwc(x2, dtype), tile=12)
+    close(nchw(y), ref, dtype, "dual-source 1x1 tile12")
+    y0 = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=nhwc(x2, dtype))
+    assert (y.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
+
+
 def test_persistent_tile_refuses_what_it_cannot_do(ops):
     """tile 12 is Linear-only (1x1, one source, K a multiple of 64 and >= 320): anything else is an error, not a silent fallback"""
     import mv_ldm_amd._lib as L
