@@ -237,6 +237,26 @@ def test_persistent_tile_two_sources(ops, dtype, n, h, c0, c1, cout):
     assert (y.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
 
 
+def test_persistent_tile_race_screen(ops):
+    """the counted-vmcnt ring, the prefetch across tile boundaries and the asm stores of tile 12 are the kind of code whose
+    hazards show up as RARE wrong tiles: the same launch, repeated while another stream keeps the memory system busy, must be
+    bit-identical every time (tools/race_screen.py is the long form: 1500 launches, 0 mismatches)"""
+    torch.manual_seed(0)
+    side, noise = torch.cuda.Stream(), torch.randn(16 << 20, device="cuda")
+    for rows, k, n, epi, res in ((150000, 320, 2560, 2, False), (70001, 384, 200, 0, True)):
+        x = torch.randn(rows, k, device="cuda").to(torch.bfloat16)
+        pw = ops.pack_weight(torch.randn(n, k, device="cuda") / k ** 0.5, torch.bfloat16, geglu=epi == 2)
+        b = torch.randn(n, device="cuda")
+        r = torch.randn(rows, n, device="cuda").to(torch.bfloat16) if res else None
+        ref = ops.linear(x, pw, b, residual=r, epilogue=epi, tile=12).clone()
+        for i in range(40):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    noise.mul_(1.0001)
+            assert torch.equal(ops.linear(x, pw, b, residual=r, epilogue=epi, tile=12), ref), (rows, i)
+    torch.cuda.synchronize()
+
+
 def test_persistent_tile_refuses_what_it_cannot_do(ops):
     """tile 12 is Linear-only (1x1, one source, K a multiple of 64 and >= 320): anything else is an error, not a silent fallback"""
     import mv_ldm_amd._lib as L
