@@ -100,7 +100,7 @@ class TrainBuilder(Builder):
         self.grads: Dict[tuple, torch.Tensor] = {}
         self.repack: List[Callable[[], None]] = []
         self.touched: set = set()
-        self.grad_writes: List[Tuple[int, int]] = []      # (op index, flat offset) of every parameter-gradient write
+        self.grad_writes: List[Tuple[int, int, int]] = []      # (op index, flat offset, numel) of every parameter-gradient write
         self._wws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)      # wgrad slabs / colsum / norm partials
         self.keep.append(self._wws)
 
@@ -124,9 +124,17 @@ class TrainBuilder(Builder):
         else:
             self._elt(L.TE_ADD, g, None, cur, 1, g.numel(), name="grad+=")
 
-    def _pgrad(self, p: nn.Parameter) -> torch.Tensor:
+    def _pgrad(self, p: nn.Parameter, through: Optional[nn.Parameter] = None) -> torch.Tensor:
+        """gradient view of `p` for the op ABOUT to be emitted (its plan index is len(self.ops)); the write is recorded as
+        the flat range [offset(p), offset(p) + numel) -- up to the end of `through` when one kernel fills several
+        parameters that are contiguous in the flat buffer (the fused QKV weight gradient)"""
         self.touched.add(id(p))
-        self.grad_writes.append((len(self.ops), self.flat.offset[id(p)]))
+        off = self.flat.offset[id(p)]
+        last = p if through is None else through
+        self.touched.add(id(last))
+        end = self.flat.offset[id(last)] + last.numel()
+        assert end > off
+        self.grad_writes.append((len(self.ops), off, end - off))
         return p.grad
 
     def touch(self, *ps):
@@ -268,9 +276,7 @@ class TrainBuilder(Builder):
                     off += n_i[i]
                 geom = dict(ho=1, wo=1, ksize=1, stride=1, pad=0, upsample=False)
                 if len(weights) == 1 or self.flat.contiguous(list(weights)):
-                    self._wgrad(x.view(rows, 1, 1, c), None, dy, sum(n_i), self._pgrad(weights[0]), geom, c, "wgrad")
-                    for w in weights[1:]:
-                        self._pgrad(w)
+                    self._wgrad(x.view(rows, 1, 1, c), None, dy, sum(n_i), self._pgrad(weights[0], through=weights[-1]), geom, c, "wgrad")
                 else:
                     off = 0
                     for i, w in enumerate(weights):
@@ -1024,16 +1030,22 @@ class MVLDMTrainer:
             tp.run(done, n_ops)
 
 
-def bucket_cut_points(grad_writes: Sequence[Tuple[int, int]], buckets: Sequence[Tuple[int, int]], n_ops: int) -> List[Tuple[int, int]]:
-    """for every bucket, the plan index right after the LAST op that writes a parameter gradient inside it; returned as
-    [(bucket, end index)] sorted by end index (the order the buckets become ready).  A bucket nothing writes to (padding,
-    zero-gradient parameters) is ready at once."""
+def bucket_cut_points(grad_writes: Sequence[Tuple[int, int, int]], buckets: Sequence[Tuple[int, int]], n_ops: int) -> List[Tuple[int, int]]:
+    """for every bucket, the plan index right after the LAST op that writes a parameter gradient anywhere inside it;
+    returned as [(bucket, end index)] sorted by end index (the order the buckets become ready).  A write is the flat range
+    [off, off + numel): it holds back EVERY bucket it overlaps -- a parameter may straddle a bucket boundary, and a bucket
+    may lie wholly inside one large parameter.  A bucket nothing writes to (padding, zero-gradient parameters) is ready
+    at once."""
     last = {k: 0 for k in range(len(buckets))}
-    for op_idx, off in grad_writes:
-        for k, (a, b) in enumerate(buckets):
-            if a <= off < b:
+    starts = [a for a, _ in buckets]
+    import bisect
+    for op_idx, off, numel in grad_writes:
+        assert numel > 0
+        k = max(bisect.bisect_right(starts, off) - 1, 0)
+        while k < len(buckets) and buckets[k][0] < off + numel:
+            if buckets[k][1] > off:
                 last[k] = max(last[k], op_idx + 1)
-                break
+            k += 1
     return sorted(((k, min(e, n_ops)) for k, e in last.items()), key=lambda t: (t[1], -t[0]))
 
 

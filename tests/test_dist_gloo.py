@@ -215,5 +215,49 @@ def test_sharded_optimizer_equals_single_process_adamw_world2():
     # bucket readiness: a bucket is cut right after the last plan op that writes a gradient inside it
     buckets = make_buckets(64, 2, 16)
     assert buckets == [(0, 16), (16, 32), (32, 48), (48, 64)]
-    cuts = bucket_cut_points([(10, 50), (11, 40), (20, 20), (21, 17), (30, 3)], buckets, 40)
+    cuts = bucket_cut_points([(10, 50, 4), (11, 40, 8), (20, 20, 4), (21, 17, 3), (30, 3, 5)], buckets, 40)
     assert cuts == [(3, 11), (2, 12), (1, 22), (0, 31)]
+
+
+def test_bucket_cut_points_hold_back_every_bucket_a_write_overlaps():
+    """a parameter that straddles a bucket boundary, and a bucket lying wholly inside one parameter, must wait for that
+    parameter's gradient write (a write is the flat range [off, off + numel), not its start offset)"""
+    from mv_ldm_amd.train import bucket_cut_points, make_buckets
+    buckets = make_buckets(64, 2, 16)
+    # op 7 writes [12, 36): starts in bucket 0, covers all of bucket 1, ends inside bucket 2; op 3 writes [60, 64)
+    cuts = dict(bucket_cut_points([(7, 12, 24), (3, 60, 4)], buckets, 20))
+    assert cuts == {0: 8, 1: 8, 2: 8, 3: 4}
+    # the tail element alone decides: [15, 17) touches buckets 0 and 1; [31, 32) is bucket 1 only; [32, 33) bucket 2 only
+    cuts = dict(bucket_cut_points([(5, 15, 2), (9, 31, 1), (2, 32, 1)], buckets, 20))
+    assert cuts == {0: 6, 1: 10, 2: 3, 3: 0}
+    # a bias gradient emitted BEFORE its weight's gradient must not release the bucket the weight's tail lies in
+    # (the layout of cross_attn_blocks_encoder.3.proj_out at the released widths with 256 MB buckets)
+    cuts = bucket_cut_points([(4, 40, 2), (6, 20, 20)], buckets, 20)         # bias at [40, 42), weight [20, 40)
+    assert dict(cuts)[1] == 7 and dict(cuts)[2] == 7            # (start-offset bookkeeping released bucket 2 after op 4)
+    # ends are clamped to the plan length
+    assert dict(bucket_cut_points([(19, 0, 64)], buckets, 20)) == {0: 20, 1: 20, 2: 20, 3: 20}
+
+
+def test_recorded_gradient_writes_cover_every_trained_parameter_exactly():
+    """the tape's (op, offset, numel) records, taken from a real (meta-free, CPU-recordable) layout: every trained parameter's
+    flat range is covered by the writes the builder recorded for it -- incl. the fused QKV weight gradient, one kernel that
+    fills three contiguous parameters"""
+    from mv_ldm_amd.train import FlatParams, TrainBuilder
+    import torch.nn as nn
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.to_q, self.to_k, self.to_v = nn.Linear(8, 8, bias=False), nn.Linear(8, 8, bias=False), nn.Linear(8, 8, bias=False)
+            self.n = nn.LayerNorm(8)
+    m = Tiny()
+    flat = FlatParams(m)
+    tb = TrainBuilder.__new__(TrainBuilder)            # bookkeeping only: no device, no ops
+    tb.flat, tb.touched, tb.grad_writes, tb.ops = flat, set(), [], [None] * 5
+    g = tb._pgrad(m.to_q.weight, through=m.to_v.weight)
+    assert g is m.to_q.weight.grad
+    assert tb.grad_writes == [(5, flat.offset[id(m.to_q.weight)], 3 * 64)]
+    assert {id(m.to_q.weight), id(m.to_v.weight)} <= tb.touched
+    tb.ops.append(None)
+    tb._pgrad(m.n.bias)
+    assert tb.grad_writes[-1] == (6, flat.offset[id(m.n.bias)], 8)
