@@ -506,13 +506,8 @@ template <typename T, int DP, bool ONES, int QB> static int launch_attn_k(AttnPa
     constexpr int VP = F32 ? (BKV + 1) : v_pitch(DV);
     constexpr int smem = (BKV * KP + (F32 ? DV * VP : BKV * VP)) * (int)sizeof(T);
     auto kern = attention_kernel<T, DP, ONES, QB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (smem > 48 * 1024)
-            MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc0;
     p.nqt = (max_q_len + BQ * QB - 1) / (BQ * QB);
     p.remap = max_q_len <= 2048;
     dim3 grid(p.nqt * p.heads * n_seg);

@@ -346,14 +346,9 @@ __global__ __launch_bounds__(256) void attention_bwd_ref_kernel(const AttnBwdPar
 template <typename T, int DP> static int launch_bwd_mfma(AttnBwdParams p, int n_seg, int max_q_len, int max_kv_len, hipStream_t s) {
     constexpr int DV = (DP + 31) / 32 * 32;
     constexpr int smem = (2 * BS * (DP + 8) + 2 * BS * bwd_v_pitch(DV)) * 2 + 2 * BS * 4;
-    static bool done = false;
-    if (!done) {
-        if (smem > 48 * 1024) {
-            MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<T, DP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<T, DP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        }
-        done = true;
-    }
+    static std::atomic<uint64_t> done0{0}, done1{0};
+    if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(attention_bwd_kernel<T, DP, 0>), smem, done0)) return rc0;
+    if (int rc1 = ensure_dyn_smem(reinterpret_cast<const void*>(attention_bwd_kernel<T, DP, 1>), smem, done1)) return rc1;
     p.ntile = (max_q_len + BR - 1) / BR;
     hipLaunchKernelGGL((attention_bwd_kernel<T, DP, 0>), dim3(p.ntile * p.heads * n_seg), dim3(256), smem, s, p);
     int rc = check_launch();

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 
 #include "../../include/mvldm.h"
@@ -32,6 +33,19 @@ int set_error(int code, const char* fmt, ...);
     do {                                                                \
         if (!(cond)) return ::mvldm::set_error(MVLDM_ERR_ARG, __VA_ARGS__); \
     } while (0)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: raise it once per (kernel, device).
+// `mask` is the kernel's own bitmap of devices already done (one `static std::atomic<uint64_t>` per launch site); a race
+// between two threads only repeats the idempotent call.
+inline int ensure_dyn_smem(const void* kern, int smem, std::atomic<uint64_t>& mask) {
+    if (smem <= 48 * 1024) return MVLDM_OK;
+    int dev = 0;
+    MVLDM_CHECK_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return MVLDM_OK;
+    MVLDM_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    mask.fetch_or(bit, std::memory_order_release);
+    return MVLDM_OK;
+}
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(MVLDM_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));

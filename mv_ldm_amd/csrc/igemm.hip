@@ -1199,20 +1199,15 @@ static const int kEnvFake = env_int("MVLDM_IGEMM_FAKE", 0);
 static constexpr int kEnvFake = 0;
 #endif
 
-template <typename KernT> static int launch_kernel(KernT kern, bool& attr_done, int smem, int blocks, int threads,
+template <typename KernT> static int launch_kernel(KernT kern, std::atomic<uint64_t>& attr_done, int smem, int blocks, int threads,
                                                    const IgemmParams& p, hipStream_t s) {
-    if (!attr_done) {
-        if (smem > 48 * 1024)
-            MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
-    }
+    if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), smem, s, p);
     return check_launch();
 }
 
 template <typename T, int BM, int BN, int WM, int WN> static int launch_sync(const IgemmParams& p, hipStream_t s) {
-    static bool done = false;
+    static std::atomic<uint64_t> done{0};
     return launch_kernel(igemm_kernel<T, BM, BN, WM, WN>, done, 2 * (BM + BN) * Mma<T>::PITCH,
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
@@ -1223,7 +1218,7 @@ static thread_local int t_force_sync = 0;
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES, bool UPS>
 static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
-    static bool done = false;
+    static std::atomic<uint64_t> done{0};
     // the epilogue parks one 32-row fp32 block per wave in the (then idle) ring
     constexpr int ring = STAGES * (BM + BN) * 128, park = WM * WN * 32 * (park_blocks(BN / WN / 32) * 32 + 4) * 4;
     return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES, UPS>, done, ring > park ? ring : park,
@@ -1270,12 +1265,12 @@ template <typename T> static int launch_halo(const IgemmParams& p, hipStream_t s
     const int hr = halo_rows_for(p.w_in);
     const int smem = 2 * hr * 128 + 3 * 128 * 128 + 128 + 1024;
     const int blocks = 8 * p.sub_m * p.sub_n;
-    static bool done0 = false, done1 = false;
+    static std::atomic<uint64_t> done0{0}, done1{0};
     if (p.c1 > 0) {
-        if (!done1) { MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done1 = true; }
+        if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(igemm_halo_kernel<T, true>), 160 * 1024, done1)) return rc0;
         hipLaunchKernelGGL((igemm_halo_kernel<T, true>), dim3(blocks), dim3(512), smem, s, p, hr);
     } else {
-        if (!done0) { MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_halo_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done0 = true; }
+        if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(igemm_halo_kernel<T, false>), 160 * 1024, done0)) return rc0;
         hipLaunchKernelGGL((igemm_halo_kernel<T, false>), dim3(blocks), dim3(512), smem, s, p, hr);
     }
     return check_launch();

@@ -452,11 +452,8 @@ bool linear_pp_applicable(const mvldm_igemm_desc& d) {
 }
 
 template <typename T, int EPI, bool RES> static int linear_pp_launch(const LinPPParams& p, int grid, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        MVLDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_pp_kernel<T, EPI, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, LP_SMEM));
-        done = true;
-    }
+    static std::atomic<uint64_t> done{0};
+    if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(linear_pp_kernel<T, EPI, RES>), LP_SMEM, done)) return rc0;
     hipLaunchKernelGGL((linear_pp_kernel<T, EPI, RES>), dim3(grid), dim3(512), LP_SMEM, s, p);
     return check_launch();
 }

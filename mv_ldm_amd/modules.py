@@ -35,23 +35,39 @@ from .runtime import from_nhwc, get_compute_dtype, require_gpu, to_nhwc
 
 
 # Kernels that update parameters in place (train.py: fused AdamW on the flat buffers) do not move torch's version counters;
-# they call `bump_weights_epoch()` instead, and every pack / plan fingerprint below carries the epoch.
-_WEIGHTS_EPOCH = [0]
+# they call `bump_weights_epoch(module)` instead: every parameter of THAT module gets the new epoch (`p._mvldm_epoch`), and every
+# pack / plan fingerprint below carries the epochs of the parameters it was built from.  Other modules (the frozen VAE next to a
+# trained denoiser) keep theirs, so their packs and recorded plans survive the optimizer step.
+_EPOCH_COUNTER = [0]
 
 
-def bump_weights_epoch() -> int:
-    _WEIGHTS_EPOCH[0] += 1
-    return _WEIGHTS_EPOCH[0]
+def bump_weights_epoch(module=None) -> int:
+    """mark the parameters of `module` (None: every later fingerprint, via the global floor) as changed in place"""
+    _EPOCH_COUNTER[0] += 1
+    e = _EPOCH_COUNTER[0]
+    if module is None:
+        _GLOBAL_FLOOR[0] = e
+    else:
+        for p in module.parameters():
+            p._mvldm_epoch = e
+    return e
+
+
+_GLOBAL_FLOOR = [0]
+
+
+def _epoch(p) -> int:
+    return max(getattr(p, "_mvldm_epoch", 0), _GLOBAL_FLOOR[0])
 
 
 def _ver(*params):
-    return (_WEIGHTS_EPOCH[0],) + tuple((p.data_ptr(), p._version, str(p.device)) for p in params if p is not None)
+    return tuple((p.data_ptr(), p._version, _epoch(p), str(p.device)) for p in params if p is not None)
 
 
 def weights_version(module) -> int:
-    """fingerprint of every parameter's (storage, in-place version): recorded plans hold raw pointers to PACKED copies of
-    the weights, so they are keyed on this and re-recorded after `load_state_dict`, an optimizer step, an EMA copy ..."""
-    return hash((_WEIGHTS_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in module.parameters()))
+    """fingerprint of every parameter's (storage, in-place version, in-place-kernel epoch): recorded plans hold raw pointers to
+    PACKED copies of the weights, so they are keyed on this and re-recorded after `load_state_dict`, an optimizer step, an EMA copy ..."""
+    return hash(tuple((p.data_ptr(), p._version, _epoch(p)) for p in module.parameters()))
 
 
 class _PackMixin:

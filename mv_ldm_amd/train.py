@@ -74,9 +74,10 @@ class FlatParams:
         self.grad.zero_()
 
     def bump(self):
-        """in-place kernel updates do not move torch's version counters: recorded INFERENCE plans key on this instead"""
+        """in-place kernel updates do not move torch's version counters: recorded INFERENCE plans / packs of THIS module key
+        on its own epoch instead (a frozen VAE next to it keeps its plans: modules.bump_weights_epoch(module))"""
         from .modules import bump_weights_epoch
-        self.epoch = bump_weights_epoch()
+        self.epoch = bump_weights_epoch(self.module)
 
     def contiguous(self, ps: Sequence[nn.Parameter]) -> bool:
         o = [self.offset[id(p)] for p in ps]
@@ -761,21 +762,31 @@ class DistributedOptimizer:
     The flat gradient is cut into buckets (contiguous ranges, sizes a multiple of `world` x 4 floats); bucket k is
     reduce-scattered as soon as the backward plan has produced it (buckets complete from the END of the buffer: the
     backward pass visits layers in reverse), rank r keeps the r-th slice of every bucket, updates the matching slice of
-    the master weights with its slice of the moments, and the slices are all-gathered back.  world = 1: no collectives.
+    the master weights with its slice of the moments, and the slices are all-gathered back.  world = 1 without a process
+    group: no collectives; world = 1 WITH a group (`collective=True`): the same reduce-scatter / all-gather calls on a one-rank
+    communicator -- the RCCL branch end to end on a single GPU (tests/test_hip_train.py), bit-identical to the plain step.
     `update` / `sumsq` default to the HIP kernels; the CPU tests inject torch implementations (there is no CPU product path)."""
 
     def __init__(self, flat: FlatParams, cfg: OptimizerCfg = None, world: int = 1, rank: int = 0, group=None,
-                 bucket_bytes: int = 256 << 20, max_norm: float = 0.1, update=None, sumsq=None, clip=None):
+                 bucket_bytes: int = 256 << 20, max_norm: float = 0.1, update=None, sumsq=None, clip=None,
+                 collective: Optional[bool] = None, effective_batch_size: Optional[int] = None):
         cfg = cfg or OptimizerCfg()
         if cfg.name != "AdamW":
             raise NotImplementedError(f"optimizer {cfg.name}: the released config trains with AdamW (baseline.yaml:63)")
         kw = dict(cfg.kwargs or {})
         self.lr0, self.betas = cfg.lr, tuple(kw.get("betas", (0.9, 0.999)))
+        if cfg.scale_lr:        # diffusion_wrapper.py:157-166: lr *= accumulate_grad_batches x devices x nodes x per-device batch size
+            if not effective_batch_size:
+                raise ValueError("OptimizerCfg.scale_lr=True needs effective_batch_size = accumulate_grad_batches x world x per-device "
+                                 "batch size (what the reference multiplies lr by, diffusion_wrapper.py:157-166)")
+            self.lr0 = cfg.lr * effective_batch_size
         self.eps, self.weight_decay = kw.get("eps", 1e-8), kw.get("weight_decay", 1e-2)
         self.sched = cfg.scheduler
         if self.sched is not None and self.sched.get("name") != "LinearLR":
             raise NotImplementedError(f"lr scheduler {self.sched.get('name')}: the released config uses LinearLR (baseline.yaml:68)")
         self.flat, self.world, self.rank, self.group, self.max_norm = flat, world, rank, group, max_norm
+        self.collective = (world > 1) if collective is None else bool(collective)
+        assert self.collective or world == 1, "world > 1 needs the collectives"
         self.buckets = make_buckets(flat.numel, world, bucket_bytes // 4)
         self.step_count = 0          # optimizer steps taken == scheduler steps taken
         dev = flat.flat.device
@@ -796,7 +807,7 @@ class DistributedOptimizer:
     # ---- gradient exchange ----
     def reduce_bucket(self, k: int, stream=None):
         """reduce-scatter bucket k of the flat gradient (sum over ranks; the loss scale already carries 1/world)"""
-        if self.world == 1:
+        if not self.collective:
             return
         import torch.distributed as dist
         a, b = self.buckets[k]
@@ -819,30 +830,34 @@ class DistributedOptimizer:
         own_sq = torch.zeros(1, dtype=torch.float32, device=g.device)
         for oa, ob in self.owned:
             own_sq += self._sumsq(g[oa:ob])                 # (a handful of scalars: bookkeeping, not the data path)
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.all_reduce(own_sq, op=dist.ReduceOp.SUM, group=self.group)
         self._clip(own_sq, self.max_norm or 0.0, self.norm)     # norm[0] = total norm, norm[1] = clip coefficient
         total = self.norm[0]
         self.step_count += 1
         lr, off = self._lr_for_step(), 0
-        for oa, ob in self.owned:
+        dist = gloo = None
+        if self.collective:
+            import torch.distributed as dist
+            gloo = dist.get_backend(self.group) == "gloo"
+        works = []
+        for (a, b), (oa, ob) in zip(self.buckets, self.owned):
             n = ob - oa
             self._update(p[oa:ob], g[oa:ob], self.exp_avg[off:off + n], self.exp_avg_sq[off:off + n], lr, self.betas, self.eps,
                          self.weight_decay, self.step_count, self.norm)
             off += n
-        if self.world > 1:
-            import torch.distributed as dist
-            if dist.get_backend(self.group) == "gloo":
-                for (a, b) in self.buckets:
-                    n = (b - a) // self.world
-                    dist.all_gather([p[a + r * n:a + (r + 1) * n] for r in range(self.world)], p[a + self.rank * n:a + (self.rank + 1) * n].clone(),
-                                    group=self.group)
-            else:                                       # in place: sendbuff == recvbuff + rank * sendcount
-                works = [dist.all_gather_into_tensor(p[a:b], p[oa:ob], group=self.group, async_op=True)
-                         for (a, b), (oa, ob) in zip(self.buckets, self.owned)]
-                for w in works:
-                    w.wait()
+            if self.collective and not gloo:
+                # in place (sendbuff == recvbuff + rank * sendcount), issued as soon as THIS bucket's slice is updated: RCCL's
+                # stream picks up behind the AdamW kernel just enqueued, so the gather of bucket k runs under the update of k+1
+                works.append(dist.all_gather_into_tensor(p[a:b], p[oa:ob], group=self.group, async_op=True))
+        if self.collective and gloo:
+            for (a, b) in self.buckets:
+                n = (b - a) // self.world
+                dist.all_gather([p[a + r * n:a + (r + 1) * n] for r in range(self.world)], p[a + self.rank * n:a + (self.rank + 1) * n].clone(),
+                                group=self.group)
+        for w in works:
+            w.wait()
         self.flat.bump()
         return float(total)
 
@@ -898,19 +913,19 @@ class MVLDMTrainer:
 
     def __init__(self, denoiser, autoencoder, scheduler, optimizer_cfg: OptimizerCfg = None, train_cfg: TrainCfg = None,
                  dtype=torch.bfloat16, world: int = 1, rank: int = 0, group=None, graph: bool = False, bucket_bytes: int = 256 << 20,
-                 rays=None):
+                 rays=None, collective: Optional[bool] = None, effective_batch_size: Optional[int] = None):
         self.denoiser, self.autoencoder, self.scheduler = denoiser, autoencoder, scheduler
         self.cfg = train_cfg or TrainCfg()
         self.dtype, self.world, self.rank, self.graph, self.rays = dtype, world, rank, graph, rays
         for p in autoencoder.parameters():           # freeze.autoencoder = true (config/main.yaml:20)
             p.requires_grad_(False)
         self.flat = _flat_padded(denoiser, world)
-        self.opt = DistributedOptimizer(self.flat, optimizer_cfg, world, rank, group, bucket_bytes, self.cfg.gradient_clip_val)
+        self.opt = DistributedOptimizer(self.flat, optimizer_cfg, world, rank, group, bucket_bytes, self.cfg.gradient_clip_val,
+                                        collective=collective, effective_batch_size=effective_batch_size)
         self.plans: Dict[tuple, TrainPlan] = {}
         self.micro = 0
         self.global_step = 0
-        self._stale = True
-        self._comm = None
+        self._weights_gen = 0          # bumped by every optimizer step; a TrainPlan re-packs lazily when it is about to run
 
     # ---- plans -------------------------------------------------------------------------------------------
     def plan_for(self, b, v_c, v_t, hl, wl) -> TrainPlan:
@@ -918,7 +933,7 @@ class MVLDMTrainer:
         tp = self.plans.get(key)
         if tp is None:
             acc = self.cfg.accumulate_grad_batches
-            use_graph = self.graph and self.world == 1
+            use_graph = self.graph and not self.opt.collective
             saved = self.flat.grad.clone() if use_graph else None       # a plan recorded mid-accumulation must not disturb it
             tp = TrainPlan(self.denoiser, self.flat, b, v_c, v_t, hl, wl, self.dtype, loss_scale=1.0 / acc,
                            grad_scale=1.0 / (acc * self.world), graph=use_graph, rays=self.rays)
@@ -928,6 +943,7 @@ class MVLDMTrainer:
             used = {id(p) for p in self.flat.params}
             missing = used - tp.touched
             assert not missing, f"{len(missing)} trained parameter(s) never entered the training graph (static exclusion list is incomplete)"
+            tp.weights_gen = self._weights_gen      # packed at record time from the current weights
             self.plans[key] = tp
         return tp
 
@@ -997,13 +1013,12 @@ class MVLDMTrainer:
             for tp in self.plans.values():
                 tp.loss.zero_()
         tp = self.prepare(batch, **choices)
-        if self._stale:
-            for p_ in self.plans.values():
-                p_.refresh_weights()
-            self._stale = False
+        if tp.weights_gen != self._weights_gen:      # only the plan about to run re-packs (cond / uncond / other shapes wait their turn)
+            tp.refresh_weights()
+            tp.weights_gen = self._weights_gen
         before = tp.loss.clone()
         last_micro = (self.micro + 1) % acc == 0
-        if self.world > 1 and last_micro:
+        if self.opt.collective and last_micro:
             self._run_overlapped(tp)
         else:
             tp.run()
@@ -1012,7 +1027,7 @@ class MVLDMTrainer:
         if last_micro:
             self.opt.step()
             self.global_step += 1
-            self._stale = True
+            self._weights_gen += 1
         return loss.squeeze(0)
 
     def _run_overlapped(self, tp: TrainPlan):

@@ -179,3 +179,45 @@ def test_full_width_training_step_runs_configs3_shape():
     assert not torch.equal(tr.flat.flat[:4096], w0)
     for a, q in zip(frozen, never_trained(den)[:3]):
         assert torch.equal(a, q)
+
+
+def test_rccl_branch_on_a_one_rank_group_equals_the_plain_step(golden, monkeypatch):
+    """`DistributedOptimizer`'s RCCL path end to end on one GPU: a 1-rank `nccl` process group, `collective=True` -- the backward
+    plan cut into segments at the bucket boundaries (`_run_overlapped`), in-place `reduce_scatter_tensor` on the real flat
+    gradient buffer while later segments run, all-reduced norm, sharded AdamW, in-place `all_gather_into_tensor` -- must leave
+    exactly the weights, losses and gradient norm of the non-distributed step (src/main.py:119-136: DDP over NCCL)."""
+    import socket
+    import torch.distributed as dist
+    from mv_ldm_amd.train import OptimizerCfg, bucket_cut_points
+    monkeypatch.setenv("MVLDM_TRAIN_AUTOTUNE", "0")         # rule-based tiles in both trainers: bit-identical kernels
+    g = golden("g9_training_step")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = []
+        for collective in (False, True):
+            tr = build_trainer(g, torch.bfloat16, optimizer_cfg=OptimizerCfg(lr=1e-3), bucket_bytes=2 << 20,
+                               group=dist.group.WORLD if collective else None, collective=collective)
+            assert tr.opt.collective == collective and len(tr.opt.buckets) > 8
+            losses = []
+            for step in range(2):
+                for ci in (0, 2):
+                    batch, ch = g9_case(g, ci)
+                    losses.append(float(tr.training_step(batch, **hip_choices(ch))))
+            torch.cuda.synchronize()
+            assert tr.global_step == 2
+            if collective:      # the overlap really cut the plan: several distinct cut points strictly inside the backward pass
+                tp = next(iter(tr.plans.values()))
+                ends = sorted({e for _, e in bucket_cut_points(tp.grad_writes, tr.opt.buckets, len(tp.plan))})
+                assert len(ends) > 4 and ends[0] > tp.n_forward_ops and ends[-1] <= len(tp.plan)
+            got.append((tr.flat.flat.clone(), tr.flat.grad.clone(), losses, float(tr.opt.norm[0])))
+            del tr
+        (w0, g0, l0, n0), (w1, g1, l1, n1) = got
+        assert l0 == l1 and n0 == n1, (l0, l1, n0, n1)
+        assert torch.equal(g0, g1), float((g0 - g1).abs().max())
+        assert torch.equal(w0, w1), float((w0 - w1).abs().max())
+    finally:
+        dist.destroy_process_group()

@@ -87,3 +87,31 @@ def test_oracle_is_not_imported_by_the_product():
     root = pathlib.Path(__file__).resolve().parent.parent / "mv_ldm_amd"
     for f in root.rglob("*.py"):
         assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), re.M), f
+
+
+def test_scale_lr_multiplies_by_the_effective_batch_size_or_refuses():
+    """diffusion_wrapper.py:157-166: `lr = effective_batch_size * lr if scale_lr else lr`"""
+    import pytest
+    import torch
+    from torch import nn
+    from mv_ldm_amd.train import DistributedOptimizer, FlatParams, OptimizerCfg
+    flat = FlatParams(nn.Linear(4, 4))
+    noop = lambda *a, **k: None
+    with pytest.raises(ValueError, match="effective_batch_size"):
+        DistributedOptimizer(flat, OptimizerCfg(lr=2e-5, scale_lr=True), update=noop, sumsq=noop, clip=noop)
+    opt = DistributedOptimizer(flat, OptimizerCfg(lr=2e-5, scale_lr=True, scheduler=None), update=noop, sumsq=noop, clip=noop,
+                               effective_batch_size=2 * 8 * 4)
+    assert abs(opt.lr() - 2e-5 * 64) < 1e-12
+    assert abs(DistributedOptimizer(flat, OptimizerCfg(lr=2e-5, scheduler=None), update=noop, sumsq=noop, clip=noop).lr() - 2e-5) < 1e-15
+
+
+def test_weight_epochs_are_per_module():
+    """an in-place optimizer step on one module must not invalidate the packs / plans of another (the frozen VAE)"""
+    from torch import nn
+    from mv_ldm_amd.modules import bump_weights_epoch, weights_version
+    a, b = nn.Linear(3, 3), nn.Linear(3, 3)
+    va, vb = weights_version(a), weights_version(b)
+    bump_weights_epoch(a)
+    assert weights_version(a) != va and weights_version(b) == vb
+    bump_weights_epoch()            # no module: everything
+    assert weights_version(b) != vb

@@ -39,14 +39,14 @@ for it in range(3):
             acc["zero_grad"] = acc.get("zero_grad", 0) + t
         tp, t = timed(lambda: tr.prepare(batch, index=1, unconditional=False))
         acc["prepare (VAE encode + staging)"] = acc.get("prepare (VAE encode + staging)", 0) + t
-        if tr._stale:
-            _, t = timed(lambda: [p.refresh_weights() for p in tr.plans.values()])
+        if tp.weights_gen != tr._weights_gen:
+            _, t = timed(tp.refresh_weights)
             acc["refresh_weights (re-pack)"] = acc.get("refresh_weights (re-pack)", 0) + t
-            tr._stale = False
+            tp.weights_gen = tr._weights_gen
         _, t = timed(tp.run)
         acc["plan (fwd + loss + bwd)"] = acc.get("plan (fwd + loss + bwd)", 0) + t
         tr.micro += 1
     _, t = timed(tr.opt.step)
     acc["optimizer step"] = acc.get("optimizer step", 0) + t
-    tr._stale = True
+    tr._weights_gen += 1
 print({k: round(v / 3, 2) for k, v in acc.items()}, "ms per optimizer step (2 micro-batches)")
