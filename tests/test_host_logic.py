@@ -115,3 +115,19 @@ def test_weight_epochs_are_per_module():
     assert weights_version(a) != va and weights_version(b) == vb
     bump_weights_epoch()            # no module: everything
     assert weights_version(b) != vb
+
+
+def test_committed_traffic_table_answers_the_default_bench_workload():
+    """`roofline.traffic` regressed to null in round 2 when the committed table lost its workload key: the default line's
+    lookup (bf16, 64 scenes, 256x256) must find the igemm and the attention family"""
+    import importlib.util
+    import os
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = types.SimpleNamespace(dtype="bf16", res=256)
+    ig, at = bench.pmc_traffic(args, 64), bench.pmc_traffic(args, 64, "attention_kernel")
+    assert ig and ig > 1e8 and at and at > 1e8
+    assert bench.pmc_traffic(args, 7) is None          # no pass for that workload: null, not a wrong number

@@ -3,7 +3,9 @@
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 bench.py ...
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py ...
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch/p_counter_collection.csv gpurun_out/pmc_write/p_counter_collection.csv out.json [192]
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch/p_counter_collection.csv gpurun_out/pmc_write/p_counter_collection.csv out.json [192] [key] [label]
+`out.json` is keyed by workload (`key`, default bf16_b64_res256 = what `bench.py` looks up: "<dtype>_b<scenes>_res<res>"); an existing
+file keeps its other keys.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
 on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled; WRITE_SIZE is taken as reported
@@ -52,6 +54,8 @@ def collect(path: str, counter: str, igemm_last: int = 0):
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
     igemm_last = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    key = sys.argv[5] if len(sys.argv) > 5 else "bf16_b64_res256"
+    label = sys.argv[6] if len(sys.argv) > 6 else ""
     ft, fc = collect(fetch_csv, "FETCH_SIZE", igemm_last)
     wt, wc = collect(write_csv, "WRITE_SIZE", igemm_last)
     res = {}
@@ -63,8 +67,16 @@ def main():
                     "write_bytes_per_launch": write_b / max(wc.get(fam, 1), 1),
                     "hbm_bytes_per_launch": fetch_b / max(fc.get(fam, 1), 1) + write_b / max(wc.get(fam, 1), 1),
                     "fetch_bytes_total": fetch_b, "write_bytes_total": write_b}
+    try:
+        with open(out) as f:
+            tab = json.load(f)
+        if "families" in tab:       # pre-round-3 un-keyed file
+            tab = {}
+    except (OSError, ValueError):
+        tab = {}
+    tab[key] = {"collected": label, "note": "FETCH_SIZE KiB x2 (gfx950 correction), WRITE_SIZE KiB as reported", "families": res}
     with open(out, "w") as f:
-        json.dump({"note": "FETCH_SIZE KiB x2 (gfx950 correction), WRITE_SIZE KiB as reported", "families": res}, f, indent=1)
+        json.dump(tab, f, indent=1)
     for fam, r in res.items():
         print(f"{fam:24s} n={r['launches']:6d} fetch/launch={r['fetch_bytes_per_launch']/1e6:9.2f} MB "
               f"write/launch={r['write_bytes_per_launch']/1e6:9.2f} MB")
