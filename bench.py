@@ -180,6 +180,11 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
         if args.op_table:
             with open(args.op_table, "w") as f:
                 json.dump([{"name": m.name, "kind": m.kind, "ms": t, "flops": m.flops, "bytes": m.bytes} for m, t in zip(tp.plan.meta, ms)], f, indent=0)
+        if world == 1 and args.dtype == "bf16" and not getattr(args, "no_parity", False):
+            # stated tolerance of the benched training dtype: the same micro-batch on the exact-f32 HIP plan (the witness proven
+            # against the oracle + autograd in tests/test_hip_train.py), same staged inputs and weights
+            from mv_ldm_amd.train import gradient_drift_vs_f32
+            out["grad_rel_err"] = gradient_drift_vs_f32(tr, batch, index=1, unconditional=False)
     return out
 
 

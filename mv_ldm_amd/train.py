@@ -1045,6 +1045,52 @@ class MVLDMTrainer:
             tp.run(done, n_ops)
 
 
+def gradient_drift_vs_f32(trainer: "MVLDMTrainer", batch, **choices) -> dict:
+    """ONE micro-batch of `trainer`'s compute dtype against the exact-f32 HIP plan of the same shape, from the SAME staged
+    inputs (VAE latents, noise, timesteps, cameras) and the same master weights: relative L2 error of the whole flat gradient,
+    ratio of the global norms, relative loss difference, and the worst per-parameter relative L2 among parameters that carry at
+    least 1e-3 of the global gradient norm.  The f32 plan is the witness that tests/test_hip_train.py proves against the
+    oracle + autograd; this is the on-GPU statement of what the 16-bit path costs at production size (bench `training.grad_rel_err`).
+    Leaves the gradient / loss accumulators zeroed; takes no optimizer step."""
+    flat = trainer.flat
+    tp = trainer.prepare(batch, **choices)
+    if tp.weights_gen != trainer._weights_gen:
+        tp.refresh_weights()
+        tp.weights_gen = trainer._weights_gen
+    b, v_c, v_t, hl, wl = tp.shape
+    acc = trainer.cfg.accumulate_grad_batches
+    ref = TrainPlan(trainer.denoiser, flat, b, v_c, v_t, hl, wl, torch.float32, loss_scale=1.0 / acc,
+                    grad_scale=1.0 / (acc * trainer.world), graph=False, rays=trainer.rays, tune=False)
+    for name in ("latents", "noise", "noise_all", "coef", "timesteps", "extr", "intr"):
+        getattr(ref, name).copy_(getattr(tp, name))
+    out = []
+    for plan in (tp, ref):
+        flat.zero_grad()
+        plan.loss.zero_()
+        plan.run()
+        torch.cuda.synchronize()
+        out.append((flat.grad.clone(), float(plan.loss) * acc))
+    flat.zero_grad()
+    tp.loss.zero_()
+    (g_lo, l_lo), (g_hi, l_hi) = out
+    n_hi = float(g_hi.double().norm())
+    worst, worst_name = 0.0, ""
+    names = {id(p): n for n, p in trainer.denoiser.named_parameters()}
+    for p in flat.params:
+        o, n = flat.offset[id(p)], p.numel()
+        pn = float(g_hi[o:o + n].double().norm())
+        if pn >= 1e-3 * n_hi:
+            e = float((g_lo[o:o + n] - g_hi[o:o + n]).double().norm()) / pn
+            if e > worst:
+                worst, worst_name = e, names.get(id(p), "?")
+    del ref
+    return {"dtype": str(trainer.dtype).replace("torch.", ""), "reference": "f32 HIP plan, same inputs and weights",
+            "micro_batch": f"{b} scenes x ({v_c} ctx + {v_t} tgt) @ {hl * 8}x{wl * 8}",
+            "grad_rel_l2": round(float((g_lo - g_hi).double().norm()) / n_hi, 5),
+            "grad_norm_ratio": round(float(g_lo.double().norm()) / n_hi, 5), "loss_rel": round(abs(l_lo - l_hi) / abs(l_hi), 6),
+            "worst_large_param_rel_l2": round(worst, 4), "worst_large_param": worst_name}
+
+
 def bucket_cut_points(grad_writes: Sequence[Tuple[int, int, int]], buckets: Sequence[Tuple[int, int]], n_ops: int) -> List[Tuple[int, int]]:
     """for every bucket, the plan index right after the LAST op that writes a parameter gradient anywhere inside it;
     returned as [(bucket, end index)] sorted by end index (the order the buckets become ready).  A write is the flat range

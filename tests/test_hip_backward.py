@@ -338,3 +338,87 @@ def test_adamw_and_gradient_clipping_match_torch(ops):
             assert relerr(p, ref.data) < 1e-6
         if not warm:
             assert relerr(p - p0.cuda(), ref.data - p0) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ production shapes
+# The cases above are small (<= 192 channels, <= 320 tokens); these are the shapes of the released model at the configs[3]
+# micro-batch (16 images): the wgrad split-K at M = 16 384 / K = 2880, the dual-source K = 23 040 conv of the up path, the
+# K = 11 520 conv at 4x4 whose 180 K-steps are split, and attention backward over 4096-5120-token segments.  fp64 references
+# (F.conv2d / explicit softmax + autograd on the host) from the same dtype-rounded inputs; same tolerances as above.
+BIG_DTYPES, BIG_IDS = [torch.float32, torch.bfloat16], ["f32", "bf16"]
+BIG_CONVS = [  # name, n, c0, c1, c_out, h
+    ("320to320_at32_x16", 16, 320, 0, 320, 32), ("2560to1280_dual_at8_x16", 16, 1280, 1280, 1280, 8), ("1280_at4_x16", 16, 1280, 0, 1280, 4)]
+
+
+@pytest.mark.parametrize("dtype", BIG_DTYPES, ids=BIG_IDS)
+@pytest.mark.parametrize("case", BIG_CONVS, ids=[c[0] for c in BIG_CONVS])
+def test_conv_gradients_at_production_shapes(ops, case, dtype):
+    _, n, c0, c1, co, h = case
+    ci = c0 + c1
+    torch.set_num_threads(min(64, __import__("os").cpu_count() or 8))
+    x, w = rnd((n, ci, h, h), 101, dtype), rnd((co, ci, 3, 3), 102, torch.float32, 1 / math.sqrt(ci * 9))
+    xd, wd = x.double().requires_grad_(), w.to(dtype).double().requires_grad_()
+    y = F.conv2d(xd, wd, None, 1, 1)
+    dy = rnd(tuple(y.shape), 103, dtype)
+    gx, gw = torch.autograd.grad(y, (xd, wd), dy.double())
+    dyd = nhwc(dy, dtype)
+    wc = w.cuda().contiguous()
+    xa = nhwc(x[:, :c0], dtype)
+    xb = nhwc(x[:, c0:], dtype) if c1 else None
+    # data gradient(s): one transposed pack per source of the skip concat
+    da = ops.conv2d(dyd, ops.pack_weight_t(wc, dtype, 0, c0))
+    assert relerr(nchw(da), gx[:, :c0]) < TOL[dtype]
+    if c1:
+        db = ops.conv2d(dyd, ops.pack_weight_t(wc, dtype, c0, c1))
+        assert relerr(nchw(db), gx[:, c0:]) < TOL[dtype]
+    # weight gradient: split over the pixel range, slabs reduced in a fixed order; then accumulated
+    grad = torch.zeros(co, ci, 3, 3, device="cuda")
+    ops.conv_wgrad(xa, dyd, grad, ksize=3, x2=xb)
+    assert relerr(grad, gw) < TOL[dtype]
+    first = grad.clone()
+    ops.conv_wgrad(xa, dyd, grad, ksize=3, x2=xb, accumulate=True)
+    assert relerr(grad, 2 * gw) < TOL[dtype]
+    again = torch.zeros_like(grad)
+    ops.conv_wgrad(xa, dyd, again, ksize=3, x2=xb)
+    assert torch.equal(again, first)            # deterministic reduction order
+
+
+BIG_ATTN = [("d40_3d_5120_4096", 8, 40, [5120, 4096]), ("d64_sd_1024x16", 5, 64, [1024] * 16)]
+
+
+@pytest.mark.parametrize("dtype", BIG_DTYPES, ids=BIG_IDS)
+@pytest.mark.parametrize("case", BIG_ATTN, ids=[c[0] for c in BIG_ATTN])
+def test_attention_backward_at_production_shapes(ops, case, dtype):
+    """level-0 3-D attention of a conditional (5 views) + an unconditional (4 views) scene, and the SD self-attention of 16
+    images, on a fused [tokens, 3C] projection; reference per (segment, head) in fp64 so that one 5120 x 5120 score matrix
+    is alive at a time"""
+    _, heads, d, lens = case
+    C_ = heads * d
+    n = sum(lens)
+    torch.set_num_threads(min(64, __import__("os").cpu_count() or 8))
+    qkv = rnd((n, 3 * C_), 111, dtype)
+    dout = rnd((n, C_), 112, dtype)
+    ref = torch.empty(n, C_, dtype=torch.float64)
+    gqkv = torch.empty(n, 3 * C_, dtype=torch.float64)
+    r0 = 0
+    for L_ in lens:
+        for hd in range(heads):
+            cs = [slice(j * C_ + hd * d, j * C_ + (hd + 1) * d) for j in range(3)]
+            q, k, v = (qkv[r0:r0 + L_, c].double().requires_grad_() for c in cs)
+            o = torch.softmax(q @ k.t() * d ** -0.5, dim=-1) @ v
+            gs = torch.autograd.grad(o, (q, k, v), dout[r0:r0 + L_, hd * d:(hd + 1) * d].double())
+            ref[r0:r0 + L_, hd * d:(hd + 1) * d] = o.detach()
+            for c, g_ in zip(cs, gs):
+                gqkv[r0:r0 + L_, c] = g_
+        r0 += L_
+    seg = ops.make_segments(lens, lens)
+    x = qkv.to(dtype).cuda()
+    q, k, v = x[:, :C_], x[:, C_:2 * C_], x[:, 2 * C_:]
+    lse = torch.zeros(heads, n, device="cuda")
+    out = ops.attention(q, k, v, heads, d, seg, max(lens), lse=lse)
+    assert relerr(out.float().cpu(), ref) < TOL[dtype] * 3
+    dqkv = torch.zeros(n, 3 * C_, dtype=dtype, device="cuda")
+    ops.attention_bwd(q, k, v, out, dout.to(dtype).cuda(), lse, heads, d, seg, max(lens), max(lens), dqkv=dqkv)
+    tol = 3e-5 if dtype == torch.float32 else TOL[dtype] * 3
+    for j, nm in enumerate("qkv"):
+        assert relerr(dqkv[:, j * C_:(j + 1) * C_].float().cpu(), gqkv[:, j * C_:(j + 1) * C_]) < tol, nm
