@@ -363,6 +363,11 @@ def ref_attention(q, k, v, heads, d, q_lens, kv_lens):
 ATTN_CASES = [  # heads, d, q_lens (kv = q: self-attention)
     (2, 8, [5]), (2, 16, [64, 64]), (3, 32, [100]), (8, 40, [320, 256]), (5, 64, [17, 256, 1]),
     (8, 80, [1280]), (8, 160, [320, 80]), (8, 40, [1029]), (1, 64, [129, 127, 128]),
+    # the ping-pong kernel (16-bit, head_dim 33..64, a query segment of >= 256 rows): padded widths 48 / 64 with and without the
+    # ones column, ragged query and key tails, one / two / many key tiles, short segments next to long ones (narrower heads: the
+    # one-block-per-wave kernel on the same shapes)
+    (2, 16, [700]), (4, 8, [513]), (3, 32, [256, 300]), (2, 24, [300]), (2, 48, [384]), (2, 56, [260, 64]), (5, 64, [1024, 1]),
+    (8, 40, [1280, 1024]), (1, 64, [256]), (2, 40, [257, 255, 63, 64, 65]),
 ]
 
 
@@ -390,6 +395,28 @@ def test_attention_cross_and_spike(ops, dtype):
     seg = ops.make_segments(ql, kl)
     y = ops.attention(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), heads, d, seg, max(ql))
     close(y.float().cpu().double(), ref, dtype, "attention cross/spike")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_attention_pingpong_cross_spike_and_lse(ops, dtype):
+    """the ping-pong kernel with kv length != q length (both ways), a late dominating key (online-softmax rescale with a large max
+    jump, in the middle of the key stream of one wave group), and the log-sum-exp it saves for the backward pass"""
+    heads, d = 4, 40
+    ql, kl = [300, 290, 33], [200, 1000, 1]
+    q, k, v = rnd((sum(ql), heads * d), 43, dtype), rnd((sum(kl), heads * d), 44, dtype), rnd((sum(kl), heads * d), 45, dtype)
+    k[150] = q[5] * 6.0          # third key tile of segment 0, query 5
+    k[200 + 777] = q[300 + 280] * 5.0   # late in segment 1, a query of the last wave
+    k = k.to(dtype).float()
+    ref = ref_attention(q, k, v, heads, d, ql, kl)
+    seg = ops.make_segments(ql, kl)
+    lse = torch.zeros(heads, sum(ql), device="cuda")
+    y = ops.attention(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), heads, d, seg, max(ql), lse=lse)
+    close(y.float().cpu().double(), ref, dtype, "ping-pong attention cross/spike")
+    q0, k0 = 0, 0
+    for a, b in zip(ql, kl):
+        sc = (q[q0:q0 + a].view(a, heads, d).transpose(0, 1).double() @ k[k0:k0 + b].view(b, heads, d).transpose(0, 1).double().transpose(1, 2)) * d ** -0.5
+        assert (lse[:, q0:q0 + a].double().cpu() - torch.logsumexp(sc, -1) / math.log(2)).abs().max() < 3e-2
+        q0, k0 = q0 + a, k0 + b
 
 
 # ------------------------------------------------------------------------------------------------ small ops
