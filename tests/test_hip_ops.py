@@ -363,9 +363,8 @@ def ref_attention(q, k, v, heads, d, q_lens, kv_lens):
 ATTN_CASES = [  # heads, d, q_lens (kv = q: self-attention)
     (2, 8, [5]), (2, 16, [64, 64]), (3, 32, [100]), (8, 40, [320, 256]), (5, 64, [17, 256, 1]),
     (8, 80, [1280]), (8, 160, [320, 80]), (8, 40, [1029]), (1, 64, [129, 127, 128]),
-    # the ping-pong kernel (16-bit, head_dim 33..64, a query segment of >= 256 rows): padded widths 48 / 64 with and without the
-    # ones column, ragged query and key tails, one / two / many key tiles, short segments next to long ones (narrower heads: the
-    # one-block-per-wave kernel on the same shapes)
+    # long query segments (>= 256 rows) at every padded width with and without the ones column, ragged query and key tails,
+    # one / two / many key tiles, short segments next to long ones
     (2, 16, [700]), (4, 8, [513]), (3, 32, [256, 300]), (2, 24, [300]), (2, 48, [384]), (2, 56, [260, 64]), (5, 64, [1024, 1]),
     (8, 40, [1280, 1024]), (1, 64, [256]), (2, 40, [257, 255, 63, 64, 65]),
 ]
@@ -398,9 +397,9 @@ def test_attention_cross_and_spike(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-def test_attention_pingpong_cross_spike_and_lse(ops, dtype):
-    """the ping-pong kernel with kv length != q length (both ways), a late dominating key (online-softmax rescale with a large max
-    jump, in the middle of the key stream of one wave group), and the log-sum-exp it saves for the backward pass"""
+def test_attention_long_cross_spike_and_lse(ops, dtype):
+    """long segments with kv length != q length (both ways), a late dominating key (online-softmax rescale with a large max jump in
+    the middle of the key stream), and the log-sum-exp saved for the backward pass"""
     heads, d = 4, 40
     ql, kl = [300, 290, 33], [200, 1000, 1]
     q, k, v = rnd((sum(ql), heads * d), 43, dtype), rnd((sum(kl), heads * d), 44, dtype), rnd((sum(kl), heads * d), 45, dtype)
@@ -411,7 +410,7 @@ def test_attention_pingpong_cross_spike_and_lse(ops, dtype):
     seg = ops.make_segments(ql, kl)
     lse = torch.zeros(heads, sum(ql), device="cuda")
     y = ops.attention(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), heads, d, seg, max(ql), lse=lse)
-    close(y.float().cpu().double(), ref, dtype, "ping-pong attention cross/spike")
+    close(y.float().cpu().double(), ref, dtype, "attention long cross/spike")
     q0, k0 = 0, 0
     for a, b in zip(ql, kl):
         sc = (q[q0:q0 + a].view(a, heads, d).transpose(0, 1).double() @ k[k0:k0 + b].view(b, heads, d).transpose(0, 1).double().transpose(1, 2)) * d ** -0.5
