@@ -666,31 +666,47 @@ def never_trained(den) -> List[nn.Parameter]:
 
 # ================================================================================================ one micro-batch plan
 class TrainPlan:
-    """input assembly + forward + loss + backward of ONE micro-batch shape as a C-side plan.
-    shape = (b scenes, v_c context views [0 = unconditional], v_t target views, hl, wl)."""
+    """input assembly + forward + loss + backward as a C-side plan, for ONE micro-batch shape (b scenes, v_c context views
+    [0 = unconditional], v_t target views) or for a whole accumulation window: `parts` = one (b, v_c, v_t) per micro-batch, the
+    scenes of all parts concatenated into one forward / backward over view groups.  Gradients of the parts sum in the same
+    kernels (the loss of part i is the mean over ITS target elements times `loss_scale`, exactly what accumulating the
+    micro-batches one by one adds up to), the weights are read once, and every launch serves the whole window."""
 
-    def __init__(self, den, flat: FlatParams, b: int, v_c: int, v_t: int, hl: int, wl: int, dtype, loss_scale: float = 1.0,
+    def __init__(self, den, flat: FlatParams, b, v_c=None, v_t=None, hl: int = 0, wl: int = 0, dtype=torch.bfloat16, loss_scale: float = 1.0,
                  grad_scale: float = 1.0, graph: bool = False, rays=None, tune: Optional[bool] = None):
         dev = flat.flat.device
         if tune is None:        # plan-time tile selection of the forward / data-gradient implicit GEMMs (MVLDM_TRAIN_AUTOTUNE=0: rules only)
             tune = os.environ.get("MVLDM_TRAIN_AUTOTUNE", "1") != "0" and os.environ.get("MVLDM_AUTOTUNE", "1") != "0"
-        self.shape = (b, v_c, v_t, hl, wl)
-        v = v_c + v_t
-        n_img, lc = b * v, den.out_channels
+        parts = [(int(b), int(v_c), int(v_t))] if v_c is not None else [tuple(int(q) for q in part) for part in b]
+        self.parts = parts
+        self.shape = parts[0] + (hl, wl) if len(parts) == 1 else (tuple(parts), hl, wl)
+        lc = den.out_channels
         e = ops.epc(dtype)
         c_pad = (den.in_channels + e - 1) // e * e
+        # image / target rows of every part inside the concatenated buffers
+        self.img0, self.tgt0, groups, tgt_rows = [], [], [], []
+        n_img = n_tgt = 0
+        for (pb, pc, pt) in parts:
+            self.img0.append(n_img)
+            self.tgt0.append(n_tgt)
+            v = pc + pt
+            groups += [v] * pb
+            tgt_rows += [n_img + s_ * v + pc + j for s_ in range(pb) for j in range(pt)]
+            n_img += pb * v
+            n_tgt += pb * pt
+        self.n_img, self.n_tgt = n_img, n_tgt
         bld = TrainBuilder(dev, dtype, flat)
-        z = lambda *s, dt_=torch.float32: torch.zeros(*s, dtype=dt_, device=dev)
+        z = lambda *s_, dt_=torch.float32: torch.zeros(*s_, dtype=dt_, device=dev)
         # ---- inputs staged by the host (copies), assembled by HIP kernels (diffusion_wrapper.py:362-398) ----
         self.latents = z(n_img, lc, hl, wl)            # first_stage_encode of [context | target] views, per scene
-        self.noise = z(b * v_t, lc, hl, wl)            # target_noise
+        self.noise = z(n_tgt, lc, hl, wl)              # target_noise
         self.coef = z(n_img, 2)                        # (sqrt(a_t), sqrt(1 - a_t)); context rows: (1, 0)
         self.timesteps = torch.zeros(n_img, dtype=torch.int64, device=dev)
         self.extr, self.intr = z(n_img, 4, 4), z(n_img, 3, 3)
-        self.loss = z(1)
-        ones = torch.ones(b * v_t, 1, hl, wl, dtype=torch.float32, device=dev)
+        self.loss = z(len(parts))                      # one accumulator per part (micro-batch)
+        ones = torch.ones(n_tgt, 1, hl, wl, dtype=torch.float32, device=dev)
         unet_in = z(n_img, hl, wl, c_pad, dt_=dtype)
-        tgt_img = torch.tensor([s * v + v_c + j for s in range(b) for j in range(v_t)], dtype=torch.int32, device=dev)
+        tgt_img = torch.tensor(tgt_rows, dtype=torch.int32, device=dev)
         # the noise buffer holds target views only; add_noise walks all images with a per-image coefficient pair, so the
         # context rows read a zero "noise" with coefficient (1, 0): give it a full-size view
         self.noise_all = z(n_img, lc, hl, wl)
@@ -704,18 +720,20 @@ class TrainPlan:
             bld.nchw_to_nhwc(ones, unet_in, lc, img_map=tgt_img, name="target mask")
             bld.ray_encode(self.extr, self.intr, hl, wl, unet_in, lc + 1, name="ray grid", **({} if rays is None else rays.kernel_args()))
         with bld.scope("unet"):
-            eps = emit_unet_train(bld, den, unet_in, self.timesteps, [v] * b)
+            eps = emit_unet_train(bld, den, unet_in, self.timesteps, groups)
         dc = (lc + e - 1) // e * e
         d_eps = z(n_img, hl, wl, dc, dt_=dtype)
         ws = torch.zeros(256, dtype=torch.float64, device=dev)
         bld.fill_zero(d_eps, "d_eps = 0")
-        op = L.Op()
-        op.kind = L.OP_MSE_LOSS
-        m = op.u.mse
-        m.pred, m.noise, m.tgt_img, m.loss, m.dpred, m.workspace = ptr(eps), ptr(self.noise), ptr(tgt_img), ptr(self.loss), ptr(d_eps), ptr(ws)
-        m.n_tgt, m.hw, m.c, m.accumulate, m.dpred_c, m.dpred_dtype = b * v_t, hl * wl, lc, 1, dc, dt(d_eps)
-        m.loss_scale, m.grad_scale = loss_scale, grad_scale
-        bld._emit(op, "mse_loss", 0.0, eps.numel() * 8.0, (eps, self.noise, tgt_img, self.loss, d_eps, ws))
+        for i, (pb, pc, pt) in enumerate(parts):        # F.mse_loss per micro-batch: the mean runs over that part's target elements
+            t0, nt = self.tgt0[i], pb * pt
+            op = L.Op()
+            op.kind = L.OP_MSE_LOSS
+            m = op.u.mse
+            m.pred, m.noise, m.tgt_img, m.loss, m.dpred, m.workspace = ptr(eps), ptr(self.noise[t0:t0 + nt]), ptr(tgt_img[t0:t0 + nt]), ptr(self.loss[i:i + 1]), ptr(d_eps), ptr(ws)
+            m.n_tgt, m.hw, m.c, m.accumulate, m.dpred_c, m.dpred_dtype = nt, hl * wl, lc, 1, dc, dt(d_eps)
+            m.loss_scale, m.grad_scale = loss_scale, grad_scale
+            bld._emit(op, "mse_loss" if len(parts) == 1 else f"mse_loss.{i}", 0.0, nt * hl * wl * lc * 8.0, (eps, self.noise, tgt_img, self.loss, d_eps, ws))
         self.n_forward_ops = len(bld.ops)
         bld.grads[_key(eps)] = d_eps
         with bld.scope("backward"):
@@ -929,13 +947,18 @@ class MVLDMTrainer:
 
     # ---- plans -------------------------------------------------------------------------------------------
     def plan_for(self, b, v_c, v_t, hl, wl) -> TrainPlan:
-        key = (b, v_c, v_t, hl, wl)
+        return self.plan_for_parts([(b, v_c, v_t)], hl, wl)
+
+    def plan_for_parts(self, parts, hl, wl) -> TrainPlan:
+        """the recorded plan of one micro-batch shape (one part) or of a whole accumulation window (one part per micro-batch)"""
+        parts = [tuple(int(q) for q in part) for part in parts]
+        key = parts[0] + (hl, wl) if len(parts) == 1 else (tuple(parts), hl, wl)
         tp = self.plans.get(key)
         if tp is None:
             acc = self.cfg.accumulate_grad_batches
             use_graph = self.graph and not self.opt.collective
             saved = self.flat.grad.clone() if use_graph else None       # a plan recorded mid-accumulation must not disturb it
-            tp = TrainPlan(self.denoiser, self.flat, b, v_c, v_t, hl, wl, self.dtype, loss_scale=1.0 / acc,
+            tp = TrainPlan(self.denoiser, self.flat, parts, None, None, hl, wl, self.dtype, loss_scale=1.0 / acc,
                            grad_scale=1.0 / (acc * self.world), graph=use_graph, rays=self.rays)
             if saved is not None:
                 self.flat.grad.copy_(saved)
@@ -948,12 +971,13 @@ class MVLDMTrainer:
         return tp
 
     # ---- the reference's training_step, host part (diffusion_wrapper.py:324-400) ---------------------------
-    def prepare(self, batch, index=None, second=None, relative_coin=None, unconditional=None, noise=None, timestep=None, encode_noise=None):
-        """returns (plan, loaded) after staging one micro-batch.  The random choices of the reference (context count
-        :336, relative vs absolute poses :346, CFG drop :381, noise :362, timesteps :363) are drawn here the same way unless
-        given explicitly (tests / reproducible runs): `second` = the second torch.randint of sample_indices (relative index, or
-        which context view is kept), `relative_coin` / `unconditional` = what the two np.random.choice calls returned."""
-        from .pipeline import VAE_SCALE, absolute_to_relative_camera
+    def _host_part(self, batch, index=None, second=None, relative_coin=None, unconditional=None, noise=None, timestep=None, encode_noise=None):
+        """the host side of one micro-batch up to (not including) the VAE encode.  The random choices of the reference (context
+        count :336, relative vs absolute poses :346, CFG drop :381, noise :362, timesteps :363) are drawn here the same way and in
+        the same order unless given explicitly (tests / reproducible runs): `second` = the second torch.randint of sample_indices
+        (relative index, or which context view is kept), `relative_coin` / `unconditional` = what the two np.random.choice calls
+        returned.  (noise / timesteps are drawn after the encode, like the reference: `_finish_part`.)"""
+        from .pipeline import absolute_to_relative_camera
         ctx, tgt = batch["context"], batch["target"]
         v_c0 = ctx["image"].shape[1]
         if index is None:
@@ -970,38 +994,75 @@ class MVLDMTrainer:
         images = torch.cat([c_img, t_img], dim=1)
         dev = self.flat.flat.device
         x = images.reshape(b * (v_c + v_t), *images.shape[2:]).to(dev, torch.float32).contiguous()
+        return dict(b=b, v_c=v_c, v_t=v_t, x=x, ext=ext, intr=intr, unconditional=unconditional, noise=noise, timestep=timestep,
+                    encode_noise=encode_noise)
+
+    def _encode(self, xs: Sequence[torch.Tensor], encode_noises: Sequence[Optional[torch.Tensor]]) -> List[torch.Tensor]:
+        """first_stage_encode (diffusion_wrapper.py:278-287) of the images of one or several micro-batches in ONE encoder call"""
+        from .pipeline import VAE_SCALE
         with torch.no_grad():
-            post = self.autoencoder.encode(x, dtype=self.dtype, pre_scale=2.0, pre_shift=-1.0).latent_dist
-            lat = post.sample(noise=encode_noise, scale=VAE_SCALE)               # [b*v, 4, hl, wl]
+            post = self.autoencoder.encode(torch.cat(list(xs), 0) if len(xs) > 1 else xs[0], dtype=self.dtype, pre_scale=2.0, pre_shift=-1.0).latent_dist
+            en = None
+            if any(n is not None for n in encode_noises):
+                assert all(n is not None for n in encode_noises), "encode_noise: give it for every micro-batch of the window or for none"
+                en = torch.cat([n.reshape(x.shape[0], -1, *n.shape[-2:]) for n, x in zip(encode_noises, xs)], 0)
+            lat = post.sample(noise=en, scale=VAE_SCALE)               # [sum b*v, 4, hl, wl]
+        return list(torch.split(lat, [x.shape[0] for x in xs], 0))
+
+    def _finish_part(self, part: dict, lat: torch.Tensor) -> dict:
+        """the draws that follow the encode in the reference (:362-381), and the effective shape of the part"""
+        dev = self.flat.flat.device
+        b, v_c, v_t = part["b"], part["v_c"], part["v_t"]
         hl, wl = lat.shape[-2:]
-        lat = lat.view(b, v_c + v_t, -1, hl, wl)
-        if unconditional is None:
-            unconditional = bool(np.random.choice([False, True], 1, p=[0.90, 0.10])[0]) if self.cfg.cfg_train else True
-        if noise is None:
-            noise = torch.randn((b, v_t, lat.shape[2], hl, wl), device=dev)
-        if timestep is None:
-            timestep = torch.randint(0, self.cfg.num_train_timesteps, size=(b,), device=dev, dtype=torch.long)
-        vc_eff = 0 if unconditional else v_c
-        tp = self.plan_for(b, vc_eff, v_t, hl, wl)
+        part["lat"] = lat.view(b, v_c + v_t, -1, hl, wl)
+        if part["unconditional"] is None:
+            part["unconditional"] = bool(np.random.choice([False, True], 1, p=[0.90, 0.10])[0]) if self.cfg.cfg_train else True
+        if part["noise"] is None:
+            part["noise"] = torch.randn((b, v_t, lat.shape[1], hl, wl), device=dev)
+        if part["timestep"] is None:
+            part["timestep"] = torch.randint(0, self.cfg.num_train_timesteps, size=(b,), device=dev, dtype=torch.long)
+        part["vc_eff"] = 0 if part["unconditional"] else v_c
+        return part
+
+    def _stage_part(self, tp: TrainPlan, i: int, part: dict):
+        """copy part i's inputs into its slice of the plan's fixed buffers (copies only: the assembly is HIP kernels of the plan)"""
+        dev = self.flat.flat.device
+        b, v_c, v_t, vc_eff = part["b"], part["v_c"], part["v_t"], part["vc_eff"]
+        assert tp.parts[i] == (b, vc_eff, v_t)
         v = vc_eff + v_t
-        keep = slice(v_c, None) if unconditional else slice(None)
-        tp.latents.copy_(lat[:, keep].reshape(tp.latents.shape))
-        tp.noise.copy_(noise.reshape(tp.noise.shape))
-        na = tp.noise_all.view(b, v, *tp.noise_all.shape[1:])
-        na[:, vc_eff:].copy_(noise.to(dev))
+        i0, t0 = tp.img0[i], tp.tgt0[i]
+        lat, noise = part["lat"], part["noise"].to(dev)
+        keep = slice(v_c, None) if part["unconditional"] else slice(None)
+        tp.latents[i0:i0 + b * v].copy_(lat[:, keep].reshape(b * v, *lat.shape[2:]))
+        tp.noise[t0:t0 + b * v_t].copy_(noise.reshape(b * v_t, *noise.shape[2:]))
+        na = tp.noise_all[i0:i0 + b * v].view(b, v, *tp.noise_all.shape[1:])
+        na[:, vc_eff:].copy_(noise)
         ac = self.scheduler.alphas_cumprod.to(dev)
-        t_dev = timestep.to(dev)
+        t_dev = part["timestep"].to(dev)
         coef = torch.zeros(b, v, 2, device=dev)
         coef[:, :vc_eff, 0] = 1.0
         coef[:, vc_eff:, 0] = (ac[t_dev] ** 0.5)[:, None]
         coef[:, vc_eff:, 1] = ((1 - ac[t_dev]) ** 0.5)[:, None]
-        tp.coef.copy_(coef.view(b * v, 2))
+        tp.coef[i0:i0 + b * v].copy_(coef.view(b * v, 2))
         ts = torch.zeros(b, v, dtype=torch.int64, device=dev)
         ts[:, vc_eff:] = t_dev[:, None]
-        tp.timesteps.copy_(ts.view(-1))
-        tp.extr.copy_(ext[:, keep].reshape(b * v, 4, 4))
-        tp.intr.copy_(intr[:, keep].reshape(b * v, 3, 3))
+        tp.timesteps[i0:i0 + b * v].copy_(ts.view(-1))
+        tp.extr[i0:i0 + b * v].copy_(part["ext"][:, keep].reshape(b * v, 4, 4))
+        tp.intr[i0:i0 + b * v].copy_(part["intr"][:, keep].reshape(b * v, 3, 3))
+
+    def prepare(self, batch, **choices) -> TrainPlan:
+        """stage ONE micro-batch into the plan of its shape (recorded on first use); returns the plan"""
+        part = self._host_part(batch, **choices)
+        part = self._finish_part(part, self._encode([part["x"]], [part["encode_noise"]])[0])
+        lat = part["lat"]
+        tp = self.plan_for(part["b"], part["vc_eff"], part["v_t"], lat.shape[-2], lat.shape[-1])
+        self._stage_part(tp, 0, part)
         return tp
+
+    def _fresh(self, tp: TrainPlan):
+        if tp.weights_gen != self._weights_gen:      # only the plan about to run re-packs (cond / uncond / other shapes wait their turn)
+            tp.refresh_weights()
+            tp.weights_gen = self._weights_gen
 
     def training_step(self, batch, **choices) -> torch.Tensor:
         """one micro-batch: forward + loss + backward (gradients accumulate in the flat buffer); every
@@ -1013,22 +1074,58 @@ class MVLDMTrainer:
             for tp in self.plans.values():
                 tp.loss.zero_()
         tp = self.prepare(batch, **choices)
-        if tp.weights_gen != self._weights_gen:      # only the plan about to run re-packs (cond / uncond / other shapes wait their turn)
-            tp.refresh_weights()
-            tp.weights_gen = self._weights_gen
-        before = tp.loss.clone()
+        self._fresh(tp)
+        before = tp.loss[0:1].clone()
         last_micro = (self.micro + 1) % acc == 0
         if self.opt.collective and last_micro:
             self._run_overlapped(tp)
         else:
             tp.run()
-        loss = (tp.loss - before) * acc
+        loss = (tp.loss[0:1] - before) * acc
         self.micro += 1
         if last_micro:
             self.opt.step()
             self.global_step += 1
             self._weights_gen += 1
         return loss.squeeze(0)
+
+    def training_window(self, batches: Sequence[dict], choices: Optional[Sequence[dict]] = None) -> torch.Tensor:
+        """a whole accumulation window -- `accumulate_grad_batches` micro-batches -- as ONE forward / loss / backward plan over the
+        concatenated scenes, then the optimizer step: the same gradients as `training_step` called once per micro-batch (each
+        part's loss is the mean over its own target elements / accumulate_grad_batches; sums differ in rounding order only),
+        with the weights read once, half the launches and one VAE-encoder call.  Returns the per-micro-batch (unscaled) losses
+        `[accumulate_grad_batches]`.  Draw order: the pre-encode choices of every micro-batch, ONE encoder call (one posterior draw
+        for all views), then each micro-batch's post-encode choices."""
+        acc = self.cfg.accumulate_grad_batches
+        assert len(batches) == acc and self.micro % acc == 0, "training_window takes one full accumulation window at its start"
+        choices = list(choices) if choices is not None else [{} for _ in batches]
+        parts = [self._host_part(bt, **ch) for bt, ch in zip(batches, choices)]
+        same_res = all(p_["x"].shape[1:] == parts[0]["x"].shape[1:] for p_ in parts)
+        if same_res:
+            lats = self._encode([p_["x"] for p_ in parts], [p_["encode_noise"] for p_ in parts])
+        else:
+            lats = [self._encode([p_["x"]], [p_["encode_noise"]])[0] for p_ in parts]
+        parts = [self._finish_part(p_, lat) for p_, lat in zip(parts, lats)]
+        hw = {tuple(p_["lat"].shape[-2:]) for p_ in parts}
+        assert len(hw) == 1, "one accumulation window, one latent resolution"
+        hl, wl = next(iter(hw))
+        self.flat.zero_grad()
+        for tp_ in self.plans.values():
+            tp_.loss.zero_()
+        tp = self.plan_for_parts([(p_["b"], p_["vc_eff"], p_["v_t"]) for p_ in parts], hl, wl)
+        for i, p_ in enumerate(parts):
+            self._stage_part(tp, i, p_)
+        self._fresh(tp)
+        if self.opt.collective:
+            self._run_overlapped(tp)
+        else:
+            tp.run()
+        losses = tp.loss * acc
+        self.micro += acc
+        self.opt.step()
+        self.global_step += 1
+        self._weights_gen += 1
+        return losses
 
     def _run_overlapped(self, tp: TrainPlan):
         """backward in segments: as soon as the last write into a bucket has been issued, its reduce-scatter starts on
@@ -1054,9 +1151,7 @@ def gradient_drift_vs_f32(trainer: "MVLDMTrainer", batch, **choices) -> dict:
     Leaves the gradient / loss accumulators zeroed; takes no optimizer step."""
     flat = trainer.flat
     tp = trainer.prepare(batch, **choices)
-    if tp.weights_gen != trainer._weights_gen:
-        tp.refresh_weights()
-        tp.weights_gen = trainer._weights_gen
+    trainer._fresh(tp)
     b, v_c, v_t, hl, wl = tp.shape
     acc = trainer.cfg.accumulate_grad_batches
     ref = TrainPlan(trainer.denoiser, flat, b, v_c, v_t, hl, wl, torch.float32, loss_scale=1.0 / acc,
@@ -1069,7 +1164,7 @@ def gradient_drift_vs_f32(trainer: "MVLDMTrainer", batch, **choices) -> dict:
         plan.loss.zero_()
         plan.run()
         torch.cuda.synchronize()
-        out.append((flat.grad.clone(), float(plan.loss) * acc))
+        out.append((flat.grad.clone(), float(plan.loss[0]) * acc))
     flat.zero_grad()
     tp.loss.zero_()
     (g_lo, l_lo), (g_hi, l_hi) = out

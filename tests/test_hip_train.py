@@ -119,6 +119,38 @@ def test_accumulation_clipping_adamw_step_vs_oracle(golden):
     assert (num / den_) ** 0.5 < 2e-2, (num / den_) ** 0.5                        # AdamW normalises tiny gradients: 1/sqrt(v) amplifies noise
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_accumulation_window_as_one_plan_equals_micro_batch_steps(golden, dtype):
+    """`training_window`: the two micro-batches of an accumulation window (different shapes: conditional 2 + 3 views, unconditional
+    3 views) as ONE forward / loss / backward plan over the concatenated scenes + the optimizer step, against `training_step`
+    called once per micro-batch: same losses, same accumulated gradient (summation order differs: f32 1e-5, bf16 2e-2 relative
+    L2 -- bf16 activation gradients are rounded per kernel, and the kernels see different row counts), same gradient norm."""
+    from mv_ldm_amd.train import OptimizerCfg
+    g = golden("g9_training_step")
+    f32 = dtype == torch.float32
+    got = []
+    for window in (False, True):
+        tr = build_trainer(g, dtype, optimizer_cfg=OptimizerCfg(lr=1e-3))
+        cases = [g9_case(g, ci) for ci in (0, 2)]
+        if window:
+            losses = tr.training_window([c[0] for c in cases], [hip_choices(c[1]) for c in cases])
+            losses = [float(x) for x in losses]
+            assert len(tr.plans) == 1 and len(next(iter(tr.plans.values())).parts) == 2
+        else:
+            losses = [float(tr.training_step(c[0], **hip_choices(c[1]))) for c in cases]
+        torch.cuda.synchronize()
+        assert tr.global_step == 1 and tr.micro == 2
+        got.append((losses, tr.flat.grad.clone(), float(tr.opt.norm[0]), tr.flat.flat.clone()))
+    (l0, g0, n0, w0), (l1, g1, n1, w1) = got
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < (1e-5 if f32 else 5e-3) * abs(a), (l0, l1)
+    e = float((g0 - g1).double().norm() / g0.double().norm())
+    assert e < (1e-5 if f32 else 2e-2), e
+    assert abs(n0 - n1) < (1e-5 if f32 else 1e-2) * n0
+    if f32:
+        assert float((w0 - w1).abs().max()) < 2e-5          # one AdamW step of lr 1e-3 from (almost) the same gradients
+
+
 def test_inference_plans_follow_in_place_optimizer_steps(golden):
     """the fused AdamW kernel updates the flat fp32 parameters in place, invisible to torch's version counters: recorded
     INFERENCE plans (raw pointers to PACKED weight copies) must be re-recorded after it (modules.bump_weights_epoch)"""
