@@ -482,6 +482,212 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const AttnParams p)
     }
 }
 
+// 16-byte chunk through a buffer descriptor: a lane whose offset is out of range (keys past the segment) reads zeros -- no
+// branch, no select, 32-bit offsets (descriptors only in free functions: hipcc's host pass, see igemm.hip)
+__device__ __forceinline__ u32x4 attn_buf_load(const void* base, unsigned bytes, unsigned voff) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+}
+
+// ---- wide heads on the matrix cores: the head dimension split over the four waves of a workgroup ----------------
+// The VAE mid-block attention is ONE head of 512 columns over 1024 tokens per image.  The flash kernel
+// above keeps O^T[d][q] and the Q fragments of a 32-query block in one wave's registers: at d = 512 that is 256 + 128 registers.
+// Here the four waves of a workgroup share the SAME 32 queries and split d into four slices of DSL = d / 4 columns:
+//     wave w:  S_w^T[key][q] = K[:, slice w] Q[:, slice w]^T      (a partial sum over its slice: DSL / 16 MFMAs per 32 keys)
+//     all:     S^T = S_0^T + S_1^T + S_2^T + S_3^T                 (exchanged through LDS; every wave then holds the full scores
+//                                                                    of its lanes' queries and runs the same online softmax)
+//     wave w:  O^T[slice w][q] += V[:, slice w]^T P^T              (its DSL output columns: DSL / 32 x 2 MFMAs per 32 keys)
+// K / V tiles of 32 keys x d are staged through LDS by all 256 threads (register prefetch of the next tile under the math, as
+// above); same transposed products, accumulator-row key order and ds_read_b64_tr_b16 V fragments as attention_kernel.
+// 16-bit types, head_dim = 4 * DSL with DSL a multiple of 32 (instantiated: DSL = 128, the VAE's 512).
+constexpr int BKW = 32;      // keys per tile
+template <typename T, int DSL>
+__global__ __launch_bounds__(256, 2)
+void attention_dsplit_kernel(const AttnParams p) {
+    static_assert(sizeof(T) == 2 && DSL % 32 == 0 && DSL <= 128, "d-split attention: 16-bit, slices of 32..128 columns");
+    using Frag = typename AttnMma<T>::Frag;
+    constexpr int EPC = 8, D = 4 * DSL;
+    constexpr int NDB = DSL / 32, NQ = DSL / 16;
+    constexpr int KP = D + 8, VP = v_pitch(D);
+    constexpr int NCH = D / EPC;                         // 16-byte chunks per K / V row
+    constexpr int NST = BKW * NCH / 256;                 // chunks per thread and matrix
+    static_assert(BKW * NCH % 256 == 0, "whole chunks per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);
+    T* Vt = Ks + BKW * KP;
+    float* Xs = reinterpret_cast<float*>(Vt + BKW * VP);     // partial scores: [wave][lane][16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int lid = p.remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int qt = lid % p.nqt, hs_ = lid / p.nqt;
+    const int head = hs_ % p.heads;
+    const int4 sg = reinterpret_cast<const int4*>(p.seg)[hs_ / p.heads];
+    const int q_row0 = sg.x, q_len = sg.y, kv_row0 = sg.z, kv_len = sg.w;
+    if (qt * 32 >= q_len) return;                        // uniform per workgroup
+    const int dsl0 = wave * DSL;                          // this wave's columns of the head
+
+    const int q_local = qt * 32 + l31;
+    const bool q_ok = q_local < q_len;
+    Frag qf[NQ];
+    {
+        const T* qp = reinterpret_cast<const T*>(p.q) + (size_t)(q_row0 + q_local) * p.ld_q + head * D + dsl0;
+#pragma unroll
+        for (int kk = 0; kk < NQ; ++kk) {
+            u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+            if (q_ok) raw = *reinterpret_cast<const u32x4*>(qp + kk * 16 + hi * 8);
+            qf[kk] = __builtin_bit_cast(Frag, raw);
+        }
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const void* const kseg = reinterpret_cast<const T*>(p.k) + (size_t)kv_row0 * p.ld_k + head * D;
+    const void* const vseg = reinterpret_cast<const T*>(p.v) + (size_t)kv_row0 * p.ld_v + head * D;
+    // extents of this (segment, head) slice: keys past kv_len are out of range and read as zeros (a segment's K / V slice stays
+    // below 4 GB: 32-bit offsets)
+    const unsigned kbytes = kv_len > 0 ? ((unsigned)(kv_len - 1) * (unsigned)p.ld_k + (unsigned)D) * 2u : 0u;
+    const unsigned vbytes = kv_len > 0 ? ((unsigned)(kv_len - 1) * (unsigned)p.ld_v + (unsigned)D) * 2u : 0u;
+    const int ntile = (kv_len + BKW - 1) / BKW;
+    // thread t holds chunk (t & (NCH-1)) of keys (t / NCH) + (256 / NCH) j of every tile
+    static_assert((NCH & (NCH - 1)) == 0 && 256 % NCH == 0, "chunks per row: a power of two");
+    constexpr int KSTEP = 256 / NCH;
+    const int st_key = tid / NCH, st_ch = tid & (NCH - 1);
+    const unsigned st_k0 = ((unsigned)st_key * (unsigned)p.ld_k + (unsigned)st_ch * EPC) * 2u;
+    const unsigned st_v0 = ((unsigned)st_key * (unsigned)p.ld_v + (unsigned)st_ch * EPC) * 2u;
+    u32x4 rk[NST], rv[NST];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const unsigned row = (unsigned)(kt * BKW + KSTEP * j);
+            rk[j] = attn_buf_load(kseg, kbytes, st_k0 + row * (unsigned)p.ld_k * 2u);
+            rv[j] = attn_buf_load(vseg, vbytes, st_v0 + row * (unsigned)p.ld_v * 2u);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            *reinterpret_cast<u32x4*>(Ks + (st_key + KSTEP * j) * KP + st_ch * EPC) = rk[j];
+            *reinterpret_cast<u32x4*>(Vt + (st_key + KSTEP * j) * VP + st_ch * EPC) = rv[j];
+        }
+    };
+    if (ntile > 0) load_tile(0);
+    const float c = p.scale_log2e;
+    const int gi = lane >> 4, sl = lane & 15;
+    const T* vsrc = Vt + (4 * (gi >> 1) + (sl >> 2)) * VP + (gi & 1) * 16 + 4 * (sl & 3) + dsl0;
+
+    for (int kt = 0; kt < ntile; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < ntile) load_tile(kt + 1);
+        // ---- partial S^T over this wave's slice of d ----
+        f32x16 s = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        {
+            const T* krow = Ks + l31 * KP + dsl0;
+#pragma unroll
+            for (int kk = 0; kk < NQ; ++kk) {
+                const auto a = *reinterpret_cast<const Frag*>(krow + kk * 16 + hi * 8);
+                s = AttnMma<T>::mma(a, qf[kk], s);
+            }
+        }
+        // ---- exchange: every wave adds the other three partial tiles (same lane = same query column / key rows) ----
+        {
+            float* mine = Xs + (wave * 64 + lane) * 16;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(mine + 4 * q4) = f32x4{s[4 * q4], s[4 * q4 + 1], s[4 * q4 + 2], s[4 * q4 + 3]};
+            __syncthreads();
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float* other = Xs + (((wave + w) & 3) * 64 + lane) * 16;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(other + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[4 * q4 + e] += t[e];
+                }
+            }
+        }
+        // (the four partial sums are added in a wave-dependent order: each wave's softmax state may differ from its neighbours'
+        //  in the last bit -- every wave normalises ITS output columns with ITS OWN denominator, so rows stay consistent)
+        if (kt == ntile - 1 && (kv_len & (BKW - 1)) != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * BKW + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                s[r] = key < kv_len ? s[r] : -INFINITY;
+            }
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        const float mc = -m_new * c;
+        l_run *= alpha;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, mc));
+            rs += s[r];
+        }
+        l_run += rs;
+        Frag pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[ks][j] = from_f32<T>(s[ks * 8 + j]);
+        // ---- O^T[slice][q] += V[:, slice]^T P^T ----
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const T* pa = vsrc + (ks * 16) * VP + db * 32;
+                const auto lo = AttnMma<T>::tr_read(pa);
+                const auto up = AttnMma<T>::tr_read(pa + 8 * VP);
+                const Frag a = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = AttnMma<T>::mma(a, pf[ks], o[db]);
+            }
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (!q_ok) return;
+    T* op = reinterpret_cast<T*>(p.out) + (size_t)(q_row0 + q_local) * p.ld_o + head * D + dsl0;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            union { T e[4]; u32x2 raw; } w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w.e[e] = from_f32<T>(o[db][r4 * 4 + e] * inv);
+            *reinterpret_cast<u32x2*>(op + db * 32 + 8 * r4 + 4 * hi) = w.raw;
+        }
+}
+
+template <typename T, int DSL> static int launch_attn_dsplit(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
+    constexpr int D = 4 * DSL;
+    constexpr int smem = (BKW * (D + 8) + BKW * v_pitch(D)) * 2 + 4 * 64 * 16 * 4;
+    auto kern = attention_dsplit_kernel<T, DSL>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc0;
+    p.nqt = (max_q_len + 31) / 32;
+    p.remap = 1;                 // all query tiles of a (head, segment) on one XCD: its K / V stream once through that L2
+    hipLaunchKernelGGL(kern, dim3(p.nqt * p.heads * n_seg), dim3(256), smem, s, p);
+    return check_launch();
+}
+
 template <typename T> static int launch_attn_wide(const AttnParams& p, int n_seg, int max_q_len, hipStream_t s) {
     const int nch = p.d / Elt<T>::EPC;
     dim3 grid((max_q_len + 3) / 4, p.heads, n_seg);
@@ -546,7 +752,13 @@ int attention_run(const void* q, const void* k, const void* v, void* out, int ld
     const int dp = (head_dim + 15) / 16 * 16;
     return dispatch_dtype(dtype, [&](auto t) {
         using T = decltype(t);
-        if (head_dim > 160) return launch_attn_wide<T>(p, n_seg, max_q_len, s);
+        if (head_dim > 160) {
+            if constexpr (sizeof(T) == 2) {       // the VAE's single 512-wide head: d split over the four waves, MFMA (MVLDM_ATTN_WIDE_VALU=1: the VALU form)
+                static const bool valu = getenv("MVLDM_ATTN_WIDE_VALU") && atoi(getenv("MVLDM_ATTN_WIDE_VALU")) != 0;
+                if (head_dim == 512 && !valu && !p.lse) return launch_attn_dsplit<T, 128>(p, n_seg, max_q_len, s);
+            }
+            return launch_attn_wide<T>(p, n_seg, max_q_len, s);
+        }
         switch (dp) {
             case 16: return launch_attn<T, 16>(p, n_seg, max_q_len, s);
             case 32: return launch_attn<T, 32>(p, n_seg, max_q_len, s);

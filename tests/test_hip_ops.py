@@ -367,6 +367,9 @@ ATTN_CASES = [  # heads, d, q_lens (kv = q: self-attention)
     # one / two / many key tiles, short segments next to long ones
     (2, 16, [700]), (4, 8, [513]), (3, 32, [256, 300]), (2, 24, [300]), (2, 48, [384]), (2, 56, [260, 64]), (5, 64, [1024, 1]),
     (8, 40, [1280, 1024]), (1, 64, [256]), (2, 40, [257, 255, 63, 64, 65]),
+    # the VAE mid-block head: one head of 512 columns (16-bit: head dimension split over the four waves on the matrix cores;
+    # f32: the VALU kernel), whole and ragged query / key tiles, two heads
+    (1, 512, [1024]), (1, 512, [100, 33, 1]), (2, 512, [65]),
 ]
 
 
