@@ -245,8 +245,12 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x0
     }
 }
 
-// widest span (channels) one workgroup can hold with <= 16 chunks per thread; 0: use the two-launch path
-static int gn_fused_plan(int hw, int c, int groups, int epc, int& nthr, int& kt) {
+// channel span one workgroup normalises (<= 16 chunks per thread); 0: use the two-launch path.  The widest span that still gives the
+// chip >= 2 workgroups per CU (large batches: fewer, fatter workgroups); small batches take the NARROWEST span instead -- at one
+// scene (9 images) the widest one left 36 workgroups of 960 threads on a 256-CU chip, 11 serial chunks each (16.7 us per launch,
+// 61 launches = 14 % of a DDIM step).  (MVLDM_GN_WIDE=1: always the widest, the round-2 rule -- A/B knob.)
+static int gn_fused_plan(int hw, int c, int groups, int epc, int n_img, int& nthr, int& kt) {
+    static const int force_wide = getenv("MVLDM_GN_WIDE") ? atoi(getenv("MVLDM_GN_WIDE")) : 0;
     const int cpg = c / groups;
     if (!((cpg >= epc && true) || (epc % cpg == 0 && epc / cpg == 2))) return 0;
     auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
@@ -259,9 +263,15 @@ static int gn_fused_plan(int hw, int c, int groups, int epc, int& nthr, int& kt)
         const int cps = span / epc;
         const int l = cps / gcd(cps, 64) * 64;
         if (l > 1024) continue;
-        const int n = 1024 / l * l;
-        const int k = (int)(((long long)hw * cps + n - 1) / n);
-        if (k <= 16) { best = span; nthr = n; kt = k; }
+        // threads: whole waves, a whole number of rows per sweep, and no more than the slab has chunks (small images)
+        int n = 1024 / l * l;
+        const long long chunks = (long long)hw * cps;
+        while (n > l && (long long)(n - l) >= chunks) n -= l;
+        const int k = (int)((chunks + n - 1) / n);
+        if (k > 16) continue;
+        const bool enough = (long long)n_img * (c / span) >= 512;
+        if (best == 0 || force_wide || enough) { best = span; nthr = n; kt = k; }
+        if (!force_wide && !enough) break;      // narrower spans already cannot fill the chip: keep the narrowest valid one
     }
     return best;
 }
@@ -399,7 +409,7 @@ int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, co
     if (n_img == 0 || hw == 0) return MVLDM_OK;
     static const int no_fused = getenv("MVLDM_GN_TWOPASS") ? atoi(getenv("MVLDM_GN_TWOPASS")) : 0;   // A/B knob
     int f_nthr = 0, f_kt = 0;
-    const int f_span = no_fused ? 0 : gn_fused_plan(hw, c, groups, epc, f_nthr, f_kt);
+    const int f_span = no_fused ? 0 : gn_fused_plan(hw, c, groups, epc, n_img, f_nthr, f_kt);
     if (f_span) {
         return dispatch_dtype(dtype, [&](auto t) {
             using T = decltype(t);
