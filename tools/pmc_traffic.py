@@ -24,7 +24,7 @@ def family(name: str) -> str:
     if "linear_pp_kernel" in name or "igemm_halo_kernel" in name:      # tiles 12 / 11 of the same implicit-GEMM family
         return "igemm"
     for key in ("igemm_bl_kernel", "igemm_kernel", "igemm_splitk_reduce", "attention_kernel",
-                "attention_wide_kernel", "gn_apply_kernel", "gn_stats_kernel", "layernorm", "eltwise", "ddim",
+                "attention_wide_kernel", "attention_dsplit_kernel", "gn_fused_kernel", "gn_apply_kernel", "gn_stats_kernel", "layernorm", "eltwise", "ddim",
                 "timestep_embed", "pack_weight", "nchw_to_nhwc", "nhwc_to_nchw"):
         if key in name:
             return "igemm" if key.startswith("igemm_") and key != "igemm_splitk_reduce" else key
