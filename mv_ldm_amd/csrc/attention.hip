@@ -80,6 +80,13 @@ __device__ __forceinline__ int vt_pos16(int t) {
     return kb * 32 + g16 * 16 + hi * 8 + j;
 }
 
+// 16-byte chunk through a buffer descriptor: a lane whose offset is out of range (keys past the segment) reads zeros -- no
+// branch, no select, 32-bit offsets (descriptors only in free functions: hipcc's host pass, see igemm.hip)
+__device__ __forceinline__ u32x4 attn_buf_load(const void* base, unsigned bytes, unsigned voff) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+}
+
 // register budget: occupancy (waves per SIMD) is what overlaps one wave's softmax with another's MFMAs; the
 // 16-bit kernels are pinned to 4 waves/SIMD (<= 128 registers) for head dims <= 64 and 3 up to 96
 // ONES (16-bit, head_dim < DP): the first zero-padding chunk of every V row holds 1.0 instead, so the PV MFMA
@@ -172,49 +179,66 @@ void attention_kernel(const AttnParams p) {
     const T* vbase = reinterpret_cast<const T*>(p.v) + (size_t)kv_row0 * p.ld_v + head * d;
     const int ntile = (kv_len + BKV - 1) / BKV;
 
-    // staging registers: chunk idx = tid + 256*j of the [64 keys][NCH chunks] tile
+    // staging registers: chunk idx = tid + 256*j of the [64 keys][NCH chunks] tile.  Loads go through a buffer descriptor over
+    // this (segment, head) slice whose base advances one tile per iteration (scalar arithmetic): a lane keeps ONE 32-bit
+    // offset per chunk and matrix, keys past kv_len are out of range and read as zeros -- no 64-bit address arithmetic, no
+    // compare, no branch in the loop (the pointer form spilled 2..8 registers at the 128-register budget of DP <= 64).
+    // Chunks that never change -- the zero padding from d to DP and, with ONES, the chunk of 1.0 right after the head in V --
+    // are written to LDS once, before the loop; their lanes then neither load nor store.
     constexpr int NST = (BKV * NCH + 255) / 256;
     Chunk<T> rk[NST], rv[NST];
-    int st_key[NST], st_ch[NST];
-    unsigned ones_bits = 0;
-    const T* st_kp[NST];
-    const T* st_vp[NST];
+    unsigned st_ko[NST], st_vo[NST], live_bits = 0;
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
         const int idx = tid + 256 * j;
-        st_key[j] = idx / NCH;
-        st_ch[j] = idx - st_key[j] * NCH;
-        const bool live = idx < BKV * NCH && st_ch[j] * EPC < d;
-        if constexpr (ONES) {   // the chunk right after the head: V gets ones there (K stays zero)
-            if (idx < BKV * NCH && st_ch[j] * EPC == d) ones_bits |= 1u << j;
-        }
-        if (!live) st_key[j] = 1 << 28;                       // never < kv_len: zero (or ones) chunk
-        st_kp[j] = kbase + (size_t)(live ? st_key[j] : 0) * p.ld_k + st_ch[j] * EPC;
-        st_vp[j] = vbase + (size_t)(live ? st_key[j] : 0) * p.ld_v + st_ch[j] * EPC;
-    }
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < NST; ++j) {
-            const bool ok = kt * BKV + st_key[j] < kv_len;
-            if (ok) {
-                rk[j] = load_chunk<T>(st_kp[j] + (size_t)kt * BKV * p.ld_k);
-                rv[j] = load_chunk<T>(st_vp[j] + (size_t)kt * BKV * p.ld_v);
-            } else {
-                rk[j].zero();
-                if constexpr (ONES) {
-                    const uint32_t f = ((ones_bits >> j) & 1u) ? (std::is_same<T, bf16_t>::value ? 0x3F803F80u : 0x3C003C00u) : 0u;
-                    rv[j].raw = u32x4{f, f, f, f};
-                } else {
-                    rv[j].zero();
+        const int key = idx / NCH, ch = idx - key * NCH;
+        const bool in_tile = idx < BKV * NCH;
+        const bool live = in_tile && ch * EPC < d;
+        if (live) live_bits |= 1u << j;
+        st_ko[j] = live ? ((unsigned)key * (unsigned)p.ld_k + (unsigned)(ch * EPC)) * (unsigned)sizeof(T) : 0xFFFFFFF0u;
+        st_vo[j] = live ? ((unsigned)key * (unsigned)p.ld_v + (unsigned)(ch * EPC)) * (unsigned)sizeof(T) : 0xFFFFFFF0u;
+        if (in_tile && !live) {
+            Chunk<T> zk, zv;
+            zk.zero();
+            zv.zero();
+            if constexpr (ONES) {
+                if (ch * EPC == d) {
+                    const uint32_t f = std::is_same<T, bf16_t>::value ? 0x3F803F80u : 0x3C003C00u;
+                    zv.raw = u32x4{f, f, f, f};
                 }
             }
+            if constexpr (F32) {
+#pragma unroll
+                for (int i = 0; i < EPC; ++i) {
+                    Ks[key * KP + ch * EPC + i] = 0.f;
+                    Vt[(ch * EPC + i) * VP + key] = 0.f;
+                }
+            } else {
+                *reinterpret_cast<u32x4*>(Ks + key * KP + ch * EPC) = zk.raw;
+                *reinterpret_cast<u32x4*>(Vt + key * VP + ch * EPC) = zv.raw;
+            }
+        }
+    }
+    // extents of the slice (a segment's K / V slice stays below 4 GB)
+    const unsigned kbytes = kv_len > 0 ? ((unsigned)(kv_len - 1) * (unsigned)p.ld_k + (unsigned)d) * (unsigned)sizeof(T) : 0u;
+    const unsigned vbytes = kv_len > 0 ? ((unsigned)(kv_len - 1) * (unsigned)p.ld_v + (unsigned)d) * (unsigned)sizeof(T) : 0u;
+    const unsigned ktile_bytes = (unsigned)BKV * (unsigned)p.ld_k * (unsigned)sizeof(T);
+    const unsigned vtile_bytes = (unsigned)BKV * (unsigned)p.ld_v * (unsigned)sizeof(T);
+    auto load_tile = [&](int kt) {
+        const unsigned ko = (unsigned)kt * ktile_bytes, vo = (unsigned)kt * vtile_bytes;      // < kbytes / vbytes: kt < ntile
+        const char* kt_base = reinterpret_cast<const char*>(kbase) + ko;
+        const char* vt_base = reinterpret_cast<const char*>(vbase) + vo;
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            rk[j].raw = attn_buf_load(kt_base, kbytes - ko, st_ko[j]);
+            rv[j].raw = attn_buf_load(vt_base, vbytes - vo, st_vo[j]);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < NST; ++j) {
             const int idx = tid + 256 * j;
-            if (idx < BKV * NCH) {
+            if ((live_bits >> j) & 1u) {
                 const int key = idx / NCH, ch = idx - key * NCH;   // (loop-invariant: hoisted by the compiler)
                 if constexpr (F32) {
 #pragma unroll
@@ -480,13 +504,6 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const AttnParams p)
             store_chunk<T>(op + ch * EPC, c);
         }
     }
-}
-
-// 16-byte chunk through a buffer descriptor: a lane whose offset is out of range (keys past the segment) reads zeros -- no
-// branch, no select, 32-bit offsets (descriptors only in free functions: hipcc's host pass, see igemm.hip)
-__device__ __forceinline__ u32x4 attn_buf_load(const void* base, unsigned bytes, unsigned voff) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
 }
 
 // ---- wide heads on the matrix cores: the head dimension split over the four waves of a workgroup ----------------
