@@ -1276,7 +1276,17 @@ template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(c
         else
             return set_error(MVLDM_ERR_ARG, "igemm: 2x2 phase conv needs tile 2, 7 or 10");
     }
-    if (p.ksize == 3) return dual ? launch_bl<T, BM, BN, WM, WN, 3, true>(p, s) : launch_bl<T, BM, BN, WM, WN, 3, false>(p, s);
+    if (p.ksize == 3) {
+        if (!dual) return launch_bl<T, BM, BN, WM, WN, 3, false>(p, s);
+        // two-source 3x3 convs: the 256x256 / 256x320 tiles do not fit the register file with a second set of per-piece offsets
+        // (hipcc: 31-33 spilled registers, 128-136 B of scratch per lane) and are not instantiated; the rules never pick them
+        // (choose_config) and an explicit request is refused.  (The UNet has no such conv: GroupNorm materialises the skip
+        // concat before conv1; only the 1x1 shortcuts read two sources.)
+        if constexpr (BM == 256 && BN >= 256)
+            return set_error(MVLDM_ERR_UNSUPPORTED, "igemm: tiles 9 / 10 do not take a two-source 3x3 conv (use tile 7 or 11)");
+        else
+            return launch_bl<T, BM, BN, WM, WN, 3, true>(p, s);
+    }
     return dual ? launch_bl<T, BM, BN, WM, WN, 1, true>(p, s) : launch_bl<T, BM, BN, WM, WN, 1, false>(p, s);
 }
 
@@ -1361,7 +1371,8 @@ static void choose_config(const mvldm_igemm_desc& d, int M, int k_tiles, int& ti
         // only ~1 workgroup per CU: needs whole rounds of 256 workgroups (sweep5: +14..33 % on the 32x32-level
         // convs / Linears at 32 scenes, a loss below ~2 rounds)
         const bool can10 = d.act_dtype != MVLDM_F32 && d.k_order == 1 && d.dst_dtype != MVLDM_F32 && d.n_pad % 320 == 0 &&
-                           d.epilogue != MVLDM_EPI_GEGLU && d.upsample != 1 && d.n_out % 8 == 0 && (d.dst_ld <= 0 || d.dst_ld % 8 == 0);
+                           d.epilogue != MVLDM_EPI_GEGLU && d.upsample != 1 && d.n_out % 8 == 0 && (d.dst_ld <= 0 || d.dst_ld % 8 == 0) &&
+                           !(d.ksize == 3 && d.src1);
         const int wgs10 = cdiv(M, 256) * (d.n_pad / 320);
         const double eff10 = (double)wgs10 / (256.0 * cdiv(wgs10, 256));
         // (Linears keep winning down to 2 ragged rounds: 908 vs 850 TFLOP/s at 576 workgroups; 3x3 convs do not)

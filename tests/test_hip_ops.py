@@ -257,6 +257,24 @@ def test_persistent_tile_race_screen(ops):
     torch.cuda.synchronize()
 
 
+def test_two_source_3x3_conv_tiles(ops):
+    """a 3x3 conv over a never-materialised channel concat: every tile that takes it agrees with the reference; the 256x256 /
+    256x320 tiles (no room for the second source's offsets without spilling) refuse instead of running slowly"""
+    dtype = torch.bfloat16
+    x, x2 = rnd((2, 128, 16, 16), 1, dtype), rnd((2, 64, 16, 16), 2, dtype)
+    wt = rnd((320, 192, 3, 3), 3, dtype, 0.05)
+    b = torch.randn(320, generator=G(4)) * 0.1
+    ref = F.conv2d(torch.cat([x, x2], 1).double(), wt.double(), b.double(), padding=1)
+    pw = ops.pack_weight(wt.cuda(), dtype, c_split=128)
+    xg, x2g = nhwc(x, dtype), nhwc(x2, dtype)
+    close(nchw(ops.conv2d(xg, pw, b.cuda(), x2=x2g)), ref, dtype, "two-source 3x3, rules")
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 11):
+        close(nchw(ops.conv2d(xg, pw, b.cuda(), x2=x2g, tile=tile, splitk=1)), ref, dtype, f"two-source 3x3 tile{tile}")
+    for tile in (9, 10):
+        with pytest.raises(RuntimeError, match="two-source 3x3"):
+            ops.conv2d(xg, pw, b.cuda(), x2=x2g, tile=tile, splitk=1)
+
+
 def test_persistent_tile_refuses_what_it_cannot_do(ops):
     """tile 12 is Linear-only (1x1, one source, K a multiple of 64 and >= 320): anything else is an error, not a silent fallback"""
     import mv_ldm_amd._lib as L
