@@ -137,6 +137,35 @@ def test_50_step_drift_of_the_16_bit_paths_vs_f32(models):
         assert out[f"b{b}_bfloat16_vs_f32_50step_latent_rel_err"] < DRIFT_TOL[torch.bfloat16], out
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_rule_based_tiles_match_the_tuned_plan(models, monkeypatch, dtype):
+    """plan-time tile selection (timed per box) only changes WHICH tile / split-K computes a product, never the product: the
+    fused CFG step recorded with `MVLDM_AUTOTUNE=0` (the rules of `choose_config`) equals the tuned plan's up to the summation
+    order of split-K slabs (f32: 1e-5; bf16: one 16-bit rounding per layer, 1e-2) -- the fallback configuration multi-rank runs
+    use for bit-identical results across ranks is the same arithmetic."""
+    M, m, _ = models
+    from mv_ldm_amd import plan as P
+    v_c, v_t, b = 1, 4, 4
+    ctx_lat, x_t, extr, intr = _inputs(v_c, v_t, b=b, seed=11)
+    outs, tiles = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MVLDM_AUTOTUNE", mode)
+        pipe = _pipe(m)
+        with M.compute_dtype(dtype):
+            st = pipe._compile(b, v_c, v_t, 32, 32, dtype, 50)
+            pipe.load_inputs(st, ctx_lat, x_t, (extr[:, :v_c], intr[:, :v_c]), (extr[:, v_c:], intr[:, v_c:]))
+            st["plan"].replay()
+            outs[mode] = pipe._read_state(st, b, v_t).cpu()
+        tiles[mode] = [t for t in st["plan"].tiles if t is not None]
+        pipe._plans.clear()
+    assert all(t == 0 for t in tiles["0"])                          # rules only
+    if dtype != torch.float32:
+        assert any(t != 0 for t in tiles["1"]) or not P._TUNE_CACHE  # the tuned plan froze at least one tile (f32 is never tuned)
+    e = rel_err(outs["1"], outs["0"])
+    print(f"tuned vs rule-based plan [{dtype}]: rel-err {e:.3e}; frozen tiles {sorted(set(tiles['1']))}")
+    assert torch.isfinite(outs["0"]).all() and e < (1e-5 if dtype == torch.float32 else 1e-2), e
+
+
 def test_plans_follow_weight_changes(models):
     """recorded plans hold pointers to PACKED copies of the weights: after `load_state_dict` (Lightning's
     load_from_checkpoint), an in-place copy or an optimizer step the next forward must use the new weights"""
