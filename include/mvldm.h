@@ -176,6 +176,16 @@ int mvldm_ddim_cfg_step(const float* eps, const float* x_t, float* x_next, const
                         const int32_t* uncond_img, int n_tgt, int hw, int c, float cfg_scale, const float* coef,
                         const int32_t* step_ptr, void* unet_in, int unet_in_c, int unet_in_dtype, int n_steps,
                         float clip_range, mvldm_stream_t stream);
+/* SCHEDULER["ddpm"].step (src/model/scheduler/__init__.py:19-22; called at diffusion_wrapper.py:451 when the config names the DDPM
+ * scheduler): diffusers' DDPMScheduler.step for epsilon prediction with variance_type "fixed_small", optionally behind the CFG compose
+ * of diffusion_wrapper.py:444 (eps_u NULL => no CFG), on flat fp32 arrays of n elements:
+ *   e = eps_u + cfg_scale (eps_c - eps_u);  x0 = (x_t - coef[0] e) / coef[1];  [x0 = clamp(x0, +-clip_range) if clip_range > 0];
+ *   x_next = coef[2] x0 + coef[3] x_t + coef[4] noise
+ * coef (device fp32 [5]) = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev) b_t / (1-a_t), sqrt(alpha_t) (1-a_prev) / (1-a_t), sqrt(variance)};
+ * the host passes coef[4] = 0 at t = 0, where diffusers adds no noise (noise may then be NULL).  Separately rounded fp32 operations in
+ * diffusers' order: bit-identical to the torch CPU expression given the same inputs. */
+int mvldm_ddpm_cfg_step(const float* eps_c, const float* eps_u, const float* x_t, const float* noise, float* x_next, size_t n,
+                        float cfg_scale, const float* coef, float clip_range, mvldm_stream_t stream);
 /* step_ptr += 1; timesteps[tgt_rows[i]] = t_table[min(step, n_steps-1)] for i < n_rows (the
  * per-image timestep vector the UNet reads: context views stay at 0, diffusion_wrapper.py:419-428) */
 int mvldm_ddim_advance(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps,
@@ -321,6 +331,11 @@ int mvldm_grad_norm(const float* g, size_t n, const float* sumsq_in, float max_n
  * g' = g * grad_scale * clip[1] (clip optional: norm_out of mvldm_grad_norm); step >= 1 is the 1-based step count. */
 int mvldm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, const float* clip, mvldm_stream_t stream);
+
+/* DiffusionWrapper.on_before_zero_grad -> self.ema.update_parameters(self.denoiser) (diffusion_wrapper.py:138-142,152-154):
+ * torch.optim.swa_utils.AveragedModel with get_ema_multi_avg_fn(0.995), i.e. avg.lerp_(p, weight) with weight = 1 - decay, on the flat
+ * fp32 parameter buffer (the first update is a plain copy, done by the caller).  avg += weight (p - avg), torch's lerp arithmetic. */
+int mvldm_ema_update(float* avg, const float* p, size_t n, float weight, mvldm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plans: a whole forward (UNet walk, VAE decoder, DDIM step) as a flat list of the ops above with

@@ -188,6 +188,8 @@ SIGNATURES = {
     "mvldm_eltwise_fwd": (C.c_int, [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp]),
     "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
     "mvldm_ddim_advance": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp]),
+    "mvldm_ddpm_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, sz, f32, vp, f32, vp]),
+    "mvldm_ema_update": (C.c_int, [vp, vp, sz, f32, vp]),
     "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, vp, vp]),
     "mvldm_ray_channels": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mvldm_ray_encode": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp] + [C.c_int] * 4 + [vp]),

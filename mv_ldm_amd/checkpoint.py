@@ -63,11 +63,12 @@ def load_unet_checkpoint(unet, path, strict: bool = True) -> "LoadReport":
 
 
 def split_wrapper_state(sd: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
-    """`denoiser.* / autoencoder.*` of a DiffusionWrapper checkpoint -> {"denoiser": {...}, "autoencoder": {...},
-    "other": {...}} with the prefixes removed.  A state dict without those prefixes is returned under "other"."""
-    out = {"denoiser": {}, "autoencoder": {}, "other": {}}
+    """`denoiser.* / autoencoder.* / ema.*` of a DiffusionWrapper checkpoint -> {"denoiser": {...}, "autoencoder": {...},
+    "ema": {...}, "other": {...}} with the prefixes removed (`ema.` = the AveragedModel of diffusion_wrapper.py:138-142: keys
+    `module.<denoiser key>` and `n_averaged`).  A state dict without those prefixes is returned under "other"."""
+    out = {"denoiser": {}, "autoencoder": {}, "ema": {}, "other": {}}
     for k, v in sd.items():
-        for part in ("denoiser", "autoencoder"):
+        for part in ("denoiser", "autoencoder", "ema"):
             if k.startswith(part + "."):
                 out[part][k[len(part) + 1:]] = v
                 break
@@ -126,12 +127,18 @@ def load_module_state(module: torch.nn.Module, sd: Dict[str, torch.Tensor], stri
     return rep
 
 
-def load_pipeline_checkpoint(pipe, path, strict: bool = True, load_autoencoder: Optional[bool] = None) -> Dict[str, LoadReport]:
+def load_pipeline_checkpoint(pipe, path, strict: bool = True, load_autoencoder: Optional[bool] = None,
+                             use_ema: bool = False) -> Dict[str, LoadReport]:
     """load a DiffusionWrapper checkpoint (Lightning `.ckpt` or the same keys as `.safetensors`) into an
     `MVLDMPipeline`.  The VAE part is optional (`load_autoencoder=None`: load it if the file has one -- released
-    checkpoints carry the frozen SD-2.1 VAE, a denoiser-only export does not)."""
+    checkpoints carry the frozen SD-2.1 VAE, a denoiser-only export does not).  `use_ema`: load the `ema.module.*` copy into
+    the denoiser instead of `denoiser.*`."""
     parts = split_wrapper_state(read_state_dict(path))
     den_sd = parts["denoiser"] or parts["other"]
+    if use_ema:      # `model.use_ema_sampling` (diffusion_wrapper.py:460-463): sample with the averaged weights
+        den_sd = {k[len("module."):]: v for k, v in parts["ema"].items() if k.startswith("module.")}
+        if not den_sd:
+            raise KeyError(f"{path}: use_ema_sampling needs the `ema.module.*` tensors of a run trained with model.ema = true")
     reports = {"denoiser": load_module_state(pipe.denoiser, den_sd, strict, "denoiser")}
     has_vae = bool(parts["autoencoder"])
     if load_autoencoder or (load_autoencoder is None and has_vae):

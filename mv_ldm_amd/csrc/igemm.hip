@@ -333,7 +333,9 @@ __device__ __forceinline__ void epi_rows(const IgemmParams& p, const float* st, 
                 const int i = rem / p.w_out, j = rem - i * p.w_out;
                 drow = ((size_t)img * (2 * p.h_out) + 2 * i + p.ph_y) * (size_t)(2 * p.w_out) + 2 * j + p.ph_x;
             }
-            store_chunk<T>(reinterpret_cast<T*>(p.dst) + drow * p.dst_ld + n0, oc);
+            T* const dptr = reinterpret_cast<T*>(p.dst) + drow * p.dst_ld + n0;
+            if (p.fake & 16) __builtin_nontemporal_store(oc.raw, reinterpret_cast<u32x4*>(dptr));    // experiment knob: streaming stores
+            else store_chunk<T>(dptr, oc);
         }
     }
 }

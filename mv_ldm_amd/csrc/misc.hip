@@ -67,6 +67,29 @@ __global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ eps
     }
 }
 
+// diffusers' DDPMScheduler.step (epsilon prediction, variance_type "fixed_small"), optionally behind the CFG compose, in the
+// order of its fp32 operations:  x0 = (x - sqrt(1-a_t) e) / sqrt(a_t)  [clamp]  ;  prev = c0 x0 + c1 x  ;  out = prev + sigma z
+// coef = {sqrt(1-a_t), sqrt(a_t), c0, c1, sigma}; sigma = 0 at t = 0 (no noise is added there; `noise` may then be null)
+__global__ __launch_bounds__(256) void ddpm_kernel(const float* __restrict__ eps_c, const float* __restrict__ eps_u,
+                                                   const float* __restrict__ x_t, const float* __restrict__ noise,
+                                                   float* __restrict__ x_next, size_t n, float cfg_scale,
+                                                   const float* __restrict__ coef, float clip_range) {
+    const float sb = coef[0], sa = coef[1], c0 = coef[2], c1 = coef[3], sigma = coef[4];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float e = eps_c[i];
+        if (eps_u) {
+            const float eu = eps_u[i];
+            e = __fadd_rn(eu, __fmul_rn(cfg_scale, __fsub_rn(e, eu)));
+        }
+        const float x = x_t[i];
+        float x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(sb, e)), sa);
+        if (clip_range > 0.f) x0 = fminf(fmaxf(x0, -clip_range), clip_range);
+        float xn = __fadd_rn(__fmul_rn(c0, x0), __fmul_rn(c1, x));
+        xn = __fadd_rn(xn, noise ? __fmul_rn(sigma, noise[i]) : 0.0f);
+        x_next[i] = xn;
+    }
+}
+
 __global__ void ddim_advance_kernel(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps,
                                     const int32_t* tgt_rows, int n_rows) {
     const int next = *step_ptr + 1;
@@ -276,6 +299,14 @@ int ddim_run(const float* eps, const float* x_t, float* x_next, const int32_t* c
     });
 }
 
+int ddpm_run(const float* eps_c, const float* eps_u, const float* x_t, const float* noise, float* x_next, size_t n, float cfg_scale,
+             const float* coef, float clip_range, hipStream_t s) {
+    if (n == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(eps_c && x_t && x_next && coef, "ddpm_step: null pointer");
+    hipLaunchKernelGGL(ddpm_kernel, dim3(grid_for(n)), dim3(256), 0, s, eps_c, eps_u, x_t, noise, x_next, n, cfg_scale, coef, clip_range);
+    return check_launch();
+}
+
 int advance_run(int32_t* step_ptr, const int64_t* t_table, int n_steps, int64_t* timesteps, const int32_t* tgt_rows,
                 int n_rows, hipStream_t s) {
     MVLDM_REQUIRE(step_ptr && t_table && n_steps > 0, "ddim_advance: bad arguments");
@@ -317,6 +348,10 @@ extern "C" int mvldm_timestep_embed_fwd(const int64_t* timesteps, const float* f
 }
 extern "C" int mvldm_eltwise_fwd(const void* x, void* y, size_t n, int op, int src_dtype, int dst_dtype, mvldm_stream_t stream) {
     return eltwise_run(x, y, n, op, src_dtype, dst_dtype, (hipStream_t)stream);
+}
+extern "C" int mvldm_ddpm_cfg_step(const float* eps_c, const float* eps_u, const float* x_t, const float* noise, float* x_next, size_t n,
+                                   float cfg_scale, const float* coef, float clip_range, mvldm_stream_t stream) {
+    return ddpm_run(eps_c, eps_u, x_t, noise, x_next, n, cfg_scale, coef, clip_range, (hipStream_t)stream);
 }
 extern "C" int mvldm_ddim_cfg_step(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img,
                                    const int32_t* uncond_img, int n_tgt, int hw, int c, float cfg_scale, const float* coef,

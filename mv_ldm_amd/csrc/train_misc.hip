@@ -271,6 +271,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// torch.optim.swa_utils.get_ema_multi_avg_fn(decay): avg.lerp_(p, 1 - decay) = avg + w (p - avg) for w < 0.5 (the form torch's lerp takes
+// there); separately rounded fp32 operations (w >= 0.5: p - (p - avg)(1 - w), torch's other branch)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ avg, const float* __restrict__ p, size_t n, float w) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float a = avg[i], q = p[i], d = __fsub_rn(q, a);
+        avg[i] = w < 0.5f ? __fadd_rn(a, __fmul_rn(w, d)) : __fsub_rn(q, __fmul_rn(d, __fsub_rn(1.0f, w)));
+    }
+}
+
 // ---- host entry points ---------------------------------------------------------------------------------------
 int colsum_run(const void* x, float* dst, float* ws, size_t ws_bytes, int n_seg, int rows_per_seg, int n, int ld, int ld_dst, int per_seg,
                int accumulate, int dtype, hipStream_t s) {
@@ -417,6 +426,13 @@ int adamw_run(float* p, const float* g, float* m, float* v, size_t n, float lr, 
     return check_launch();
 }
 
+int ema_run(float* avg, const float* p, size_t n, float weight, hipStream_t s) {
+    if (n == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(avg && p && weight >= 0.f && weight <= 1.f, "ema_update: bad arguments");
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, avg, p, n, weight);
+    return check_launch();
+}
+
 }  // namespace mvldm
 
 using namespace mvldm;
@@ -447,4 +463,7 @@ extern "C" int mvldm_grad_norm(const float* g, size_t n, const float* sumsq_in, 
 extern "C" int mvldm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, float grad_scale, const float* clip, mvldm_stream_t stream) {
     return adamw_run(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, clip, (hipStream_t)stream);
+}
+extern "C" int mvldm_ema_update(float* avg, const float* p, size_t n, float weight, mvldm_stream_t stream) {
+    return ema_run(avg, p, n, weight, (hipStream_t)stream);
 }

@@ -353,6 +353,17 @@ def ddim_cfg_step(eps, x_t, cond_img, uncond_img, cfg_scale, coef, step_ptr, une
     return out
 
 
+def ddpm_cfg_step(eps_c, eps_u, x_t, noise, cfg_scale, coef, clip_range: float = 0.0) -> torch.Tensor:
+    """diffusers `DDPMScheduler.step` (epsilon, fixed_small) behind the optional CFG compose, on flat fp32 tensors of equal size.
+    coef: device fp32 [5] = {sqrt(1-a_t), sqrt(a_t), c_x0, c_xt, sigma}; `noise` None when sigma = 0 (t = 0)."""
+    for t in (eps_c, eps_u, x_t, noise):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == x_t.numel())
+    out = torch.empty_like(x_t)
+    L.check(L.load().mvldm_ddpm_cfg_step(eps_c.data_ptr(), ptr(eps_u), x_t.data_ptr(), ptr(noise), out.data_ptr(), x_t.numel(),
+                                         cfg_scale, coef.data_ptr(), clip_range, stream()))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ training kernels
 def conv_wgrad(x, dy, grad, *, ksize, stride=1, pad=None, upsample=False, x2=None, c_in=None, accumulate=False, n_out=None) -> torch.Tensor:
     """x (x2): NHWC forward input(s); dy: NHWC / `[m, ld]` upstream gradient (columns [0, n_out)); grad: fp32 PyTorch-layout
@@ -473,3 +484,9 @@ def adamw_step(p, g, m, v, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, 
     assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v))
     L.check(L.load().mvldm_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1], eps,
                                       weight_decay, step, grad_scale, ptr(clip), stream()))
+
+
+def ema_update(avg, p, weight: float):
+    """avg.lerp_(p, weight) on flat fp32 buffers (torch.optim.swa_utils EMA: weight = 1 - decay)"""
+    assert avg.dtype == p.dtype == torch.float32 and avg.is_contiguous() and p.is_contiguous() and avg.numel() == p.numel()
+    L.check(L.load().mvldm_ema_update(avg.data_ptr(), p.data_ptr(), avg.numel(), float(weight), stream()))

@@ -25,7 +25,7 @@ import torch
 from . import ops
 from .mvunet import MultiViewUNet
 from .plan import Builder
-from .runtime import get_compute_dtype
+from .runtime import compute_dtype, get_compute_dtype
 from .scheduler import DDIMScheduler
 from .vae import AutoencoderKL
 
@@ -169,7 +169,8 @@ class MVLDMPipeline:
         return img.reshape(b, v, *img.shape[1:])
 
     # ---- the reference's step, literally (diffusion_wrapper.py:413-453) ----------------------------
-    def step(self, model, x_t, ts, context_inputs, ray_encodings, target_mask):
+    def step(self, model, x_t, ts, context_inputs, ray_encodings, target_mask, step_generator=None, step_noise=None):
+        """`step_generator` / `step_noise`: the per-step variance noise of an ancestral (DDPM) scheduler; ignored by DDIM"""
         b, v_c = context_inputs.shape[:2]
         v_t = x_t.shape[1]
         dev = x_t.device
@@ -182,9 +183,18 @@ class MVLDMPipeline:
         if self.cfg.use_cfg:
             inputs_u = torch.cat([target_inputs, ray_encodings[:, v_c:]], dim=2)
             pred_u = model.forward(inputs_u, t_tgt[:, None].expand(b, v_t))
+            if self._ancestral():        # CFG compose + DDPM update (+ fresh noise): one fused HIP kernel
+                return self.scheduler.step(pred_c[:, v_c:].contiguous(), ts, x_t, model_output_uncond=pred_u.contiguous(),
+                                           cfg_scale=self.cfg.cfg_scale, generator=step_generator, variance_noise=step_noise).prev_sample
             # CFG compose + DDIM update: one fused HIP kernel
             return self._cfg_ddim(pred_c[:, v_c:].contiguous(), pred_u, x_t, ts)
+        if self._ancestral():
+            return self.scheduler.step(pred_c[:, v_c:].contiguous(), ts, x_t, generator=step_generator, variance_noise=step_noise).prev_sample
         return self.scheduler.step(pred_c[:, v_c:].contiguous(), ts, x_t).prev_sample
+
+    def _ancestral(self) -> bool:
+        from .scheduler import DDPMScheduler
+        return isinstance(self.scheduler, DDPMScheduler)
 
     def _cfg_ddim(self, pred_c, pred_u, x_t, ts):
         dev = x_t.device
@@ -307,10 +317,12 @@ class MVLDMPipeline:
                          (tgt["extrinsics"], tgt["intrinsics"]))
         return st
 
-    def sample(self, batch, x_T=None, encode_noise=None, decode: bool = True, dtype=None):
+    def sample(self, batch, x_T=None, encode_noise=None, decode: bool = True, dtype=None, step_generator=None, step_noise=None):
         """diffusion_wrapper.py:455-490.  batch: {"context": {image [b,v_c,3,H,W], extrinsics, intrinsics},
         "target": {extrinsics [b,v_t,4,4], intrinsics}}.  `x_T` / `encode_noise`: explicit noise (the
         reference draws x_T on the CPU generator, :473)."""
+        if self._ancestral():
+            return self._sample_ancestral(batch, x_T, encode_noise, decode, dtype, step_generator, step_noise)
         st = self.prepare(batch, x_T, encode_noise, dtype)
         for _ in range(len(self.scheduler.timesteps)):
             st["plan"].replay()
@@ -318,3 +330,25 @@ class MVLDMPipeline:
         v_t = batch["target"]["extrinsics"].shape[1]
         x0 = self._read_state(st, b, v_t)
         return (self.last_stage_decode(x0) if decode else None), x0
+
+    def _sample_ancestral(self, batch, x_T, encode_noise, decode, dtype, step_generator, step_noise):
+        """`sample()` with `SCHEDULER["ddpm"]`: the reference's loop as written (diffusion_wrapper.py:455-490) -- per step the two
+        denoiser forwards (each one recorded plan), then CFG compose + ancestral update + fresh noise in one HIP kernel.  Not
+        captured into a single graph: every step draws new noise.  `step_noise`: [n_steps, b, v_t, c, hl, wl] explicit draws."""
+        dtype = dtype or get_compute_dtype()
+        ctx, tgt = batch["context"], batch["target"]
+        dev = self.device
+        ctx_lat = self.first_stage_encode(ctx["image"], noise=encode_noise)
+        b, v_c, c, hl, wl = ctx_lat.shape
+        v_t = tgt["extrinsics"].shape[1]
+        if x_T is None:
+            x_T = torch.randn((b, v_t, c, hl, wl))
+        x_t = self._scaled_noise(x_T).to(dev, torch.float32)
+        rays = ray_encode(ctx["extrinsics"], ctx["intrinsics"], tgt["extrinsics"], tgt["intrinsics"], hl, wl, device=dev, cfg=self.rays)
+        ctx_in = torch.cat([ctx_lat.to(dev, torch.float32), torch.zeros(b, v_c, 1, hl, wl, device=dev)], dim=2)
+        mask = torch.ones(b, v_t, 1, hl, wl, device=dev)
+        with compute_dtype(dtype):
+            for i, t in enumerate(self.scheduler.timesteps):
+                z = None if step_noise is None else step_noise[i]
+                x_t = self.step(self.denoiser, x_t, t, ctx_in, rays, mask, step_generator=step_generator, step_noise=z)
+        return (self.last_stage_decode(x_t) if decode else None), x_t

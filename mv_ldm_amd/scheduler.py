@@ -145,14 +145,64 @@ class DDIMScheduler:
 
 
 class DDPMScheduler(DDIMScheduler):
-    """`SCHEDULER["ddpm"]` (src/model/scheduler/__init__.py:19-22).  The reference only ever STEPS the DDIM scheduler
-    (config/model/scheduler/ddim.yaml; SURVEY.md §2 #6 marks DDPM stepping out of scope); what training uses of either
-    class -- the beta tables and `add_noise` (diffusion_wrapper.py:370) -- is identical and inherited.  Ancestral
-    sampling (`step`) needs the posterior variance and fresh noise per step: not on the path, refused loudly."""
+    """`SCHEDULER["ddpm"]` (src/model/scheduler/__init__.py:19-22): diffusers' `DDPMScheduler` for epsilon prediction with
+    `variance_type="fixed_small"` and leading timestep spacing (its defaults; `clip_sample=True` by default, like diffusers).
+    The beta tables, `set_timesteps` and `add_noise` are the DDIM class's (identical in diffusers); `step` is ancestral sampling:
+        x0 = (x_t - sqrt(1-a_t) eps) / sqrt(a_t) [clipped];  x_prev = c0 x0 + c1 x_t + sqrt(var_t) z,  z ~ N(0, 1) for t > 0
+        c0 = sqrt(a_prev) b_t / (1-a_t),  c1 = sqrt(alpha_t) (1-a_prev) / (1-a_t),  alpha_t = a_t / a_prev,  b_t = 1 - alpha_t,
+        var_t = clamp((1-a_prev) / (1-a_t) b_t, 1e-20)
+    with the scalars from 0-d fp32 torch ops (as diffusers computes them) and the elementwise update in the HIP kernel
+    `mvldm_ddpm_cfg_step`.  The released config samples with DDIM (config/model/scheduler/ddim.yaml); SURVEY.md §2 #6."""
 
-    def step(self, *a, **kw):
-        raise NotImplementedError("DDPMScheduler.step (ancestral sampling) is not on the reference's released path; "
-                                  "use the DDIM scheduler for sampling")
+    def __init__(self, *a, variance_type: str = "fixed_small", **kw):
+        super().__init__(*a, **kw)
+        if variance_type != "fixed_small":
+            raise NotImplementedError(f"variance_type {variance_type!r}: only diffusers' default 'fixed_small'")
+        self.config.variance_type = variance_type
+        self.one = torch.tensor(1.0)
+
+    def previous_timestep(self, timestep: int) -> int:
+        n = self.num_inference_steps or self.config.num_train_timesteps
+        return int(timestep) - self.config.num_train_timesteps // n
+
+    def step_coefficients(self, timestep: int) -> torch.Tensor:
+        """fp32 [5] = sqrt(1-a_t), sqrt(a_t), c0, c1, sigma (sigma = 0 at t = 0: diffusers adds no noise there)"""
+        t = int(timestep)
+        prev_t = self.previous_timestep(t)
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        b_t, b_p = 1 - a_t, 1 - a_p
+        cur_alpha = a_t / a_p
+        cur_beta = 1 - cur_alpha
+        c0 = (a_p ** 0.5 * cur_beta) / b_t
+        c1 = cur_alpha ** 0.5 * b_p / b_t
+        var = torch.clamp((1 - a_p) / (1 - a_t) * cur_beta, min=1e-20)
+        sigma = var ** 0.5 if t > 0 else torch.tensor(0.0)
+        return torch.stack([b_t ** 0.5, a_t ** 0.5, c0, c1, sigma]).float()
+
+    def coefficient_table(self) -> torch.Tensor:
+        return torch.stack([self.step_coefficients(int(t)) for t in self.timesteps]).contiguous()
+
+    def step(self, model_output, timestep, sample, generator=None, variance_noise=None, model_output_uncond=None,
+             cfg_scale: float = 0.0, **_unused):
+        """`.prev_sample` of diffusers' `DDPMScheduler.step(model_output, timestep, sample, generator)`.  `variance_noise` (same
+        shape) replaces the draw; otherwise z is drawn on the sample's device with `generator` / the global generator, as
+        diffusers' `randn_tensor` does.  `model_output_uncond` + `cfg_scale`: fuse the CFG compose of diffusion_wrapper.py:444."""
+        if not sample.is_cuda:
+            raise RuntimeError("DDPMScheduler.step runs the HIP kernel: tensors must be on the GPU (no CPU fallback)")
+        t = int(timestep)
+        coef = self.step_coefficients(t).to(sample.device)
+        z = None
+        if t > 0:
+            if variance_noise is None:
+                gdev = generator.device if generator is not None else sample.device
+                variance_noise = torch.randn(model_output.shape, generator=generator, device=gdev, dtype=torch.float32)
+            z = variance_noise.to(sample.device, torch.float32).contiguous().view(-1)
+        x = sample.float().contiguous().view(-1)
+        e = model_output.float().contiguous().view(-1)
+        eu = None if model_output_uncond is None else model_output_uncond.float().contiguous().view(-1)
+        out = ops.ddpm_cfg_step(e, eu, x, z, float(cfg_scale), coef, clip_range=self.clip_range)
+        return SimpleNamespace(prev_sample=out.view(sample.shape))
 
 
 SCHEDULER = {"ddim": DDIMScheduler, "ddpm": DDPMScheduler}

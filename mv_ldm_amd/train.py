@@ -25,6 +25,8 @@ the updated weights (RCCL over xGMI via torch.distributed; gloo in the CPU tests
 """
 from __future__ import annotations
 
+import contextlib
+
 import ctypes as C
 import math
 import os
@@ -925,13 +927,69 @@ class TrainCfg:
     num_train_timesteps: int = 1000      # config/model/scheduler/ddim.yaml:4
 
 
+class EMAWeights:
+    """`self.ema = AveragedModel(self.denoiser, multi_avg_fn=get_ema_multi_avg_fn(0.995))` + `self.ema.update_parameters(self.denoiser)`
+    (diffusion_wrapper.py:138-142,152-154; `model.ema`, off in the released config) on the flat parameter buffer: ONE fused HIP
+    kernel (`mvldm_ema_update`: avg.lerp_(p, 1 - decay), torch's arithmetic) per update instead of a foreach over ~1500 tensors.
+    Like AveragedModel the first update copies the parameters.  Parameters outside the flat buffer (never trained here) are
+    constant, so their average is themselves.  `state_dict()` uses AveragedModel's key layout (`module.<name>`, `n_averaged`), i.e.
+    what a DiffusionWrapper checkpoint stores under `ema.`."""
+
+    def __init__(self, flat: FlatParams, decay: float = 0.995):
+        self.flat, self.decay = flat, float(decay)
+        self.avg = flat.flat.clone()                 # AveragedModel deep-copies the model at construction
+        self.n_averaged = 0
+
+    def update(self):
+        from . import ops
+        if self.n_averaged == 0:
+            self.avg.copy_(self.flat.flat)
+        else:
+            ops.ema_update(self.avg, self.flat.flat, 1.0 - self.decay)
+        self.n_averaged += 1
+
+    def _names(self):
+        by_id = {id(p): n for n, p in self.flat.module.named_parameters()}
+        return [(by_id[id(p)], p) for p in self.flat.params], [(by_id[id(p)], p) for p in self.flat.excluded]
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        trained, _ = self._names()
+        sd = {"module." + k: v.detach().clone() for k, v in self.flat.module.state_dict().items()}     # untrained parameters, buffers
+        for n, p in trained:
+            o = self.flat.offset[id(p)]
+            sd["module." + n] = self.avg[o:o + p.numel()].view(p.shape).detach().clone()
+        sd["n_averaged"] = torch.tensor(self.n_averaged, dtype=torch.long)
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        trained, _ = self._names()
+        with torch.no_grad():
+            for n, p in trained:
+                o = self.flat.offset[id(p)]
+                self.avg[o:o + p.numel()].copy_(sd["module." + n].reshape(-1))
+        self.n_averaged = int(sd.get("n_averaged", torch.tensor(1)))
+
+    @contextlib.contextmanager
+    def applied(self):
+        """`model = self.ema` (use_ema_sampling, diffusion_wrapper.py:460-463): the averaged weights in place of the live ones
+        for the duration of the block (recorded inference plans re-pack on entry and on exit)"""
+        live = self.flat.flat.clone()
+        self.flat.flat.copy_(self.avg)
+        self.flat.bump()
+        try:
+            yield self.flat.module
+        finally:
+            self.flat.flat.copy_(live)
+            self.flat.bump()
+
+
 class MVLDMTrainer:
     """`DiffusionWrapper` + the Lightning loop for the training path: `training_step(batch)` per micro-batch, an optimizer
     step every `accumulate_grad_batches` micro-batches."""
 
     def __init__(self, denoiser, autoencoder, scheduler, optimizer_cfg: OptimizerCfg = None, train_cfg: TrainCfg = None,
                  dtype=torch.bfloat16, world: int = 1, rank: int = 0, group=None, graph: bool = False, bucket_bytes: int = 256 << 20,
-                 rays=None, collective: Optional[bool] = None, effective_batch_size: Optional[int] = None):
+                 rays=None, collective: Optional[bool] = None, effective_batch_size: Optional[int] = None, ema_decay: Optional[float] = None):
         self.denoiser, self.autoencoder, self.scheduler = denoiser, autoencoder, scheduler
         self.cfg = train_cfg or TrainCfg()
         self.dtype, self.world, self.rank, self.graph, self.rays = dtype, world, rank, graph, rays
@@ -944,6 +1002,9 @@ class MVLDMTrainer:
         self.micro = 0
         self.global_step = 0
         self._weights_gen = 0          # bumped by every optimizer step; a TrainPlan re-packs lazily when it is about to run
+        # `model.ema` (diffusion_wrapper.py:138-142): Lightning calls on_before_zero_grad -> ema.update_parameters at the START of
+        # every accumulation window (before its zero_grad), so the average sees theta_0 first and lags the optimizer by one step
+        self.ema = EMAWeights(self.flat, ema_decay) if ema_decay is not None else None
 
     # ---- plans -------------------------------------------------------------------------------------------
     def plan_for(self, b, v_c, v_t, hl, wl) -> TrainPlan:
@@ -1070,6 +1131,8 @@ class MVLDMTrainer:
         micro-batch's (unscaled) loss as a device scalar."""
         acc = self.cfg.accumulate_grad_batches
         if self.micro % acc == 0:
+            if self.ema is not None:
+                self.ema.update()
             self.flat.zero_grad()
             for tp in self.plans.values():
                 tp.loss.zero_()
@@ -1109,6 +1172,8 @@ class MVLDMTrainer:
         hw = {tuple(p_["lat"].shape[-2:]) for p_ in parts}
         assert len(hw) == 1, "one accumulation window, one latent resolution"
         hl, wl = next(iter(hw))
+        if self.ema is not None:
+            self.ema.update()
         self.flat.zero_grad()
         for tp_ in self.plans.values():
             tp_.loss.zero_()

@@ -71,3 +71,51 @@ class DDIMScheduler:
         while sa.ndim < original_samples.ndim:
             sa, so = sa.unsqueeze(-1), so.unsqueeze(-1)
         return sa * original_samples + so * noise
+
+
+class DDPMScheduler(DDIMScheduler):
+    """diffusers==0.27.2 `DDPMScheduler` restated for what `SCHEDULER["ddpm"]` (src/model/scheduler/__init__.py:19-22) can reach
+    through `DiffusionWrapper.step` (diffusion_wrapper.py:451): epsilon prediction, `variance_type="fixed_small"`, leading
+    spacing; tables / `set_timesteps` / `add_noise` as the DDIM class.  Published algorithm (Ho et al. 2020, eq. 7 + the
+    posterior variance), operations in diffusers' order.  Parity unpinned by the reference (package absent, never stepped by the
+    released config); cross-checked against an independent fp64 evaluation in tests/test_scheduler.py."""
+
+    def __init__(self, *a, variance_type: str = "fixed_small", **kw):
+        super().__init__(*a, **kw)
+        assert variance_type == "fixed_small"
+        self.one = torch.tensor(1.0)
+
+    def previous_timestep(self, timestep):
+        n = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
+        return timestep - self.config.num_train_timesteps // n
+
+    def _get_variance(self, t):
+        prev_t = self.previous_timestep(t)
+        alpha_prod_t = self.alphas_cumprod[t]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        current_beta_t = 1 - alpha_prod_t / alpha_prod_t_prev
+        variance = (1 - alpha_prod_t_prev) / (1 - alpha_prod_t) * current_beta_t
+        return torch.clamp(variance, min=1e-20)
+
+    def step(self, model_output, timestep, sample, generator=None, variance_noise=None):
+        t = int(timestep)
+        prev_t = self.previous_timestep(t)
+        alpha_prod_t = self.alphas_cumprod[t]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        beta_prod_t = 1 - alpha_prod_t
+        beta_prod_t_prev = 1 - alpha_prod_t_prev
+        current_alpha_t = alpha_prod_t / alpha_prod_t_prev
+        current_beta_t = 1 - current_alpha_t
+        pred_original_sample = (sample - beta_prod_t ** 0.5 * model_output) / alpha_prod_t ** 0.5
+        if self.config.clip_sample:
+            pred_original_sample = pred_original_sample.clamp(-self.config.clip_sample_range, self.config.clip_sample_range)
+        pred_original_sample_coeff = (alpha_prod_t_prev ** 0.5 * current_beta_t) / beta_prod_t
+        current_sample_coeff = current_alpha_t ** 0.5 * beta_prod_t_prev / beta_prod_t
+        pred_prev_sample = pred_original_sample_coeff * pred_original_sample + current_sample_coeff * sample
+        variance = 0
+        if t > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, dtype=model_output.dtype)
+            variance = (self._get_variance(t) ** 0.5) * variance_noise
+        pred_prev_sample = pred_prev_sample + variance
+        return SimpleNamespace(prev_sample=pred_prev_sample, pred_original_sample=pred_original_sample)

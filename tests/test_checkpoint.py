@@ -66,6 +66,30 @@ def test_round_trip(tmp_path, fmt):
             assert ka == kb and torch.equal(va, vb), ka
 
 
+def test_use_ema_sampling_loads_the_averaged_copy(tmp_path):
+    """`model.use_ema_sampling` (diffusion_wrapper.py:460-463): a DiffusionWrapper checkpoint of a run with `model.ema = true` holds
+    the AveragedModel under `ema.module.*` / `ema.n_averaged`; `use_ema=True` loads THAT copy into the denoiser"""
+    src, avg, dst = small_pipeline(1), small_pipeline(5), small_pipeline(2)
+    sd = CK.wrapper_state_dict(src)
+    sd.update({"ema.module." + k: v.detach().clone() for k, v in avg.denoiser.state_dict().items()})
+    sd["ema.n_averaged"] = torch.tensor(1234)
+    path = tmp_path / "last.ckpt"
+    torch.save({"state_dict": sd}, path)
+    parts = CK.split_wrapper_state(sd)
+    assert len(parts["ema"]) == len(avg.denoiser.state_dict()) + 1 and not parts["other"]
+    rep = CK.load_pipeline_checkpoint(dst, path)
+    assert rep["denoiser"].ok()
+    assert torch.equal(dst.denoiser.unet.conv_in.weight, src.denoiser.unet.conv_in.weight)
+    rep = CK.load_pipeline_checkpoint(dst, path, use_ema=True)
+    assert rep["denoiser"].ok() and rep["denoiser"].loaded == len(avg.denoiser.state_dict())
+    for (ka, va), (kb, vb) in zip(avg.denoiser.state_dict().items(), dst.denoiser.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    plain = tmp_path / "no_ema.ckpt"
+    torch.save({"state_dict": CK.wrapper_state_dict(src)}, plain)
+    with pytest.raises(KeyError, match="use_ema_sampling"):
+        CK.load_pipeline_checkpoint(dst, plain, use_ema=True)
+
+
 def test_strictness_old_vae_names_and_linear_conv_reshape(tmp_path):
     src, dst = small_pipeline(3), small_pipeline(4)
     sd = CK.wrapper_state_dict(src)

@@ -584,6 +584,37 @@ def test_upsample_conv_as_four_phase_convs(ops, dtype, n, c, cout, h, w, tile):
         close(nchw(ys), ref, dtype, f"phases, split-K {sk}")
 
 
+def test_ddpm_step_bit_exact(ops):
+    """`SCHEDULER["ddpm"]`: the ancestral update of `mv_ldm_amd.scheduler.DDPMScheduler.step` (HIP kernel, host-side scalars) is
+    bit-identical to the restated diffusers `DDPMScheduler.step` on the CPU, with and without `clip_sample`, with the CFG compose
+    fused in front (against compose-then-step on the CPU), at t = 0 (no noise) and for a device-side draw (same generator seed)"""
+    from mv_ldm_amd.scheduler import DDPMScheduler
+    from oracle.scheduler import DDPMScheduler as OracleDDPM
+    g = G(11)
+    x, ec, eu, z = (torch.randn(2, 4, 4, 16, 16, generator=g) for _ in range(4))
+    x = x * 1.7
+    for clip in (False, True):
+        h, o = DDPMScheduler(clip_sample=clip), OracleDDPM(clip_sample=clip)
+        h.set_timesteps(50)
+        o.set_timesteps(50)
+        for t in (980, 500, 20, 0):
+            want = o.step(ec, t, x, variance_noise=z).prev_sample
+            got = h.step(ec.cuda(), torch.tensor(t), x.cuda(), variance_noise=z.cuda()).prev_sample
+            assert torch.equal(got.cpu(), want), (clip, t, float((got.cpu() - want).abs().max()))
+            e = eu + 3.0 * (ec - eu)
+            want = o.step(e, t, x, variance_noise=z).prev_sample
+            got = h.step(ec.cuda(), t, x.cuda(), variance_noise=z.cuda(), model_output_uncond=eu.cuda(), cfg_scale=3.0).prev_sample
+            assert torch.equal(got.cpu(), want), ("cfg", clip, t)
+    h = DDPMScheduler(clip_sample=False)
+    h.set_timesteps(50)
+    a = h.step(ec.cuda(), 500, x.cuda(), generator=torch.Generator(device="cuda").manual_seed(5)).prev_sample
+    b = h.step(ec.cuda(), 500, x.cuda(), generator=torch.Generator(device="cuda").manual_seed(5)).prev_sample
+    c = h.step(ec.cuda(), 500, x.cuda(), generator=torch.Generator(device="cuda").manual_seed(6)).prev_sample
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        h.step(ec, 500, x)
+
+
 def test_ddim_clip_sample_and_step_clamp_bit_exact(ops):
     """diffusers' default `clip_sample=True` (x0 clamped to +-1 inside the fused kernel) against the oracle scheduler,
     bit for bit; and a step counter beyond the table re-applies the LAST row instead of reading out of bounds"""

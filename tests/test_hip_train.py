@@ -176,6 +176,47 @@ def test_inference_plans_follow_in_place_optimizer_steps(golden):
     assert float((y1 - y0).abs().max()) > 0, "inference plan still runs the pre-step packed weights"
 
 
+def test_ema_follows_torch_averaged_model(golden):
+    """`model.ema` (diffusion_wrapper.py:138-142,152-154): the fused flat-buffer EMA against torch's own
+    `AveragedModel(denoiser, multi_avg_fn=get_ema_multi_avg_fn(0.995)).update_parameters(denoiser)`, called where Lightning calls
+    `on_before_zero_grad` -- at the start of every accumulation window -- over three optimizer steps of the HIP trainer: the
+    averaged parameters agree bit for bit (same lerp arithmetic), the first update is a copy, and sampling `with ema.applied()`
+    runs the averaged weights and restores the live ones."""
+    import copy
+    from torch.optim.swa_utils import AveragedModel, get_ema_multi_avg_fn
+    from mv_ldm_amd.train import OptimizerCfg
+    g = golden("g9_training_step")
+    tr = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-2), ema_decay=0.995)
+    den = tr.denoiser
+    ref = AveragedModel(copy.deepcopy(den).cpu(), multi_avg_fn=get_ema_multi_avg_fn(0.995))     # a CPU twin fed with the HIP trainer's weights
+    live = copy.deepcopy(den).cpu()
+    batch, ch = g9_case(g, 0)
+    for step in range(3):
+        live.load_state_dict({k: v.detach().cpu() for k, v in den.state_dict().items()})
+        ref.update_parameters(live)                       # what on_before_zero_grad does, before this window's backward
+        for _ in range(2):
+            tr.training_step(batch, **hip_choices(ch))
+        assert tr.ema.n_averaged == step + 1 == int(ref.n_averaged)
+        got = tr.ema.state_dict()
+        want = ref.state_dict()
+        assert set(got) == set(want), set(got) ^ set(want)
+        for k, v in want.items():
+            assert torch.equal(got[k].cpu(), v), (step, k, float((got[k].cpu() - v).abs().max()))
+    assert tr.global_step == 3
+    # the average lags: it has seen theta_0 (copy), theta_1, theta_2 -- not the weights after the third step
+    name = "unet.conv_out.bias"
+    assert not torch.equal(tr.ema.state_dict()["module." + name].cpu(), dict(den.named_parameters())[name].detach().cpu())
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    lat = torch.randn(1, 3, 11, 16, 16, device="cuda", generator=gen)
+    ts = torch.tensor([10], device="cuda")
+    with torch.no_grad():
+        y_live = den(lat, ts).float().clone()
+        with tr.ema.applied():
+            y_ema = den(lat, ts).float().clone()
+        y_back = den(lat, ts).float().clone()
+    assert torch.equal(y_live, y_back) and float((y_ema - y_live).abs().max()) > 0
+
+
 def test_full_width_training_step_runs_configs3_shape():
     """BASELINE.json configs[3] per-GPU micro-batch at FULL width: 4 scenes x (2 ctx + 3 tgt) views x 256x256, bf16: one
     accumulation window (2 micro-batches) + optimizer step; size-independent checks only (finite loss of the expected
