@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include <type_traits>
 
@@ -90,6 +91,12 @@ template <typename T> __device__ __forceinline__ Chunk<T> load_chunk(const T* p)
 }
 template <typename T> __device__ __forceinline__ void store_chunk(T* p, const Chunk<T>& c) {
     *reinterpret_cast<u32x4*>(p) = c.raw;
+}
+// host: should a kernel that writes `bytes` of output use streaming stores?  Outputs of half the 256 MB Infinity Cache or more;
+// MVLDM_STREAM_STORES=0 / 1 forces it (A/B knob).
+static inline int stream_stores(size_t bytes) {
+    static const int force = getenv("MVLDM_STREAM_STORES") ? atoi(getenv("MVLDM_STREAM_STORES")) : -1;
+    return force >= 0 ? force : (bytes >= ((size_t)128 << 20));
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

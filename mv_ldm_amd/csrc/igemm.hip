@@ -42,6 +42,7 @@ struct IgemmParams {
     int fake;                      // EXPERIMENT knob (MVLDM_IGEMM_FAKE): bit 2 = no global stores / residual loads, bit 3 = no epilogue
     unsigned src0_bytes, src1_bytes, w_bytes;   // buffer-descriptor extents (lean 16-bit loop)
     int use_bl, stage_epi;
+    int nt_store;                  // staged epilogue: streaming (non-temporal) output stores
 };
 
 // ---- per-dtype MFMA + LDS policy -------------------------------------------------------------------
@@ -334,7 +335,7 @@ __device__ __forceinline__ void epi_rows(const IgemmParams& p, const float* st, 
                 drow = ((size_t)img * (2 * p.h_out) + 2 * i + p.ph_y) * (size_t)(2 * p.w_out) + 2 * j + p.ph_x;
             }
             T* const dptr = reinterpret_cast<T*>(p.dst) + drow * p.dst_ld + n0;
-            if (p.fake & 16) __builtin_nontemporal_store(oc.raw, reinterpret_cast<u32x4*>(dptr));    // experiment knob: streaming stores
+            if (p.nt_store) __builtin_nontemporal_store(oc.raw, reinterpret_cast<u32x4*>(dptr));
             else store_chunk<T>(dptr, oc);
         }
     }
@@ -1468,6 +1469,10 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     }
     p.src0_bytes = (unsigned)b0; p.src1_bytes = (unsigned)b1; p.w_bytes = (unsigned)bw;
     p.fake = kEnvFake;
+    // An output of half the 256 MB Infinity Cache or more is gone from every cache before its consumer starts: written with
+    // streaming stores it does not evict the operand tiles the other workgroups are re-reading (-0.4 % per DDIM step at 64 scenes,
+    // same-box A/B); small outputs (a few scenes) stay cacheable for the next op.  MVLDM_STREAM_STORES=0 / 1 forces it.
+    p.nt_store = stream_stores((size_t)p.M * (size_t)p.n_dst * (p.dst_f32 || d.act_dtype == MVLDM_F32 ? 4 : 2));
     if (kEnvFake & 1) p.src0_bytes = p.src1_bytes = 0;   // EXPERIMENT ONLY: every A piece fails the range check (zeros, no L2 traffic)
     if (kEnvFake & 2) p.w_bytes = 0;                     // same for W
     if (tile >= 6 && !p.use_bl) tile = 2;

@@ -272,11 +272,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // torch.optim.swa_utils.get_ema_multi_avg_fn(decay): avg.lerp_(p, 1 - decay) = avg + w (p - avg) for w < 0.5 (the form torch's lerp takes
-// there); separately rounded fp32 operations (w >= 0.5: p - (p - avg)(1 - w), torch's other branch)
+// there; w >= 0.5: p - (p - avg)(1 - w), torch's other branch)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ avg, const float* __restrict__ p, size_t n, float w) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float a = avg[i], q = p[i], d = __fsub_rn(q, a);
-        avg[i] = w < 0.5f ? __fadd_rn(a, __fmul_rn(w, d)) : __fsub_rn(q, __fmul_rn(d, __fsub_rn(1.0f, w)));
+        avg[i] = w < 0.5f ? fmaf(w, d, a) : fmaf(-d, __fsub_rn(1.0f, w), q);      // ATen's lerp: fmadd(weight, diff, start) in its vectorised form
     }
 }
 

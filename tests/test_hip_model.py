@@ -153,6 +153,60 @@ def test_step_and_sample_vs_reference_golden(M, golden, dtype):
         assert e_img < 2 * TOL_MODEL[dtype], (ci, "sample", e_img)
 
 
+def test_ddpm_ancestral_sampling_vs_oracle(M):
+    """`SCHEDULER["ddpm"]` through `sample()`: the reference's loop (diffusion_wrapper.py:455-490) with diffusers' DDPMScheduler --
+    5 ancestral steps with CFG, explicit x_T and per-step variance noise -- on the HIP path (f32) against `oracle.pipeline.sample`
+    with the restated DDPMScheduler consuming the same noise; latents within the north-star 1e-3"""
+    from mv_ldm_amd.mvunet import MultiViewUNet
+    from mv_ldm_amd.pipeline import MVLDMPipeline, SamplerCfg
+    from mv_ldm_amd.scheduler import DDPMScheduler
+    from mv_ldm_amd.vae import AutoencoderKL
+    from oracle import multiview as MV
+    from oracle import pipeline as OPL
+    from oracle.scheduler import DDPMScheduler as OracleDDPM
+    from oracle.vae import AutoencoderKL as OracleVAE
+    widths = (64, 64, 128, 128)
+    over = dict(block_out_channels=widths, attention_head_dim=tuple(max(1, c // 64) for c in widths))
+    o = MV.MultiViewUNet(MV.MVUNetCfg(autoencoder=MV.UNetCfg(block_out_channels=widths), pretrained_from="stabilityai/stable-diffusion-2-1",
+                                      pretrained_overrides=over), 11, 4).eval()
+    ovae = OracleVAE(block_out_channels=(32, 32, 64, 64), layers_per_block=1).eval()
+    den = MultiViewUNet(sd_cfg(M, widths), 11, 4)
+    vae = AutoencoderKL.from_pretrained("x", config_overrides=dict(block_out_channels=(32, 32, 64, 64), layers_per_block=1))
+    load_seeded(o, 410), load_seeded(den, 410), load_seeded(ovae, 411), load_seeded(vae, 411)
+    g = torch.Generator().manual_seed(9)
+    b, v_c, v_t, res = 1, 1, 2, 64
+    ctx_img = torch.rand(b, v_c, 3, res, res, generator=g)
+    extr, intr = random_cameras(b, v_c + v_t, seed=17)
+    x_T = torch.randn(b, v_t, 4, res // 8, res // 8, generator=g)
+    enc_noise = torch.randn(b * v_c, 4, res // 8, res // 8, generator=g)
+    z = torch.randn(5, b, v_t, 4, res // 8, res // 8, generator=g)
+
+    class Queued(OracleDDPM):           # the oracle scheduler fed with the same per-step draws
+        def step(self, model_output, timestep, sample, **kw):
+            i = self.timesteps.tolist().index(int(timestep))
+            return super().step(model_output, timestep, sample, variance_noise=z[i])
+
+    osch = Queued(clip_sample=False)
+    osch.set_timesteps(5)
+    with torch.no_grad():
+        _, want = OPL.sample(o, ovae, osch, ctx_img, extr[:, :v_c], intr[:, :v_c], extr[:, v_c:], intr[:, v_c:], x_T=x_T,
+                             encode_noise=enc_noise, decode=False)
+    sch = DDPMScheduler(clip_sample=False)
+    pipe = MVLDMPipeline(den.cuda(), vae.cuda(), sch, SamplerCfg(True, 3.0, 5))
+    pipe.set_timesteps(5)
+    batch = {"context": {"image": ctx_img, "extrinsics": extr[:, :v_c], "intrinsics": intr[:, :v_c]},
+             "target": {"extrinsics": extr[:, v_c:], "intrinsics": intr[:, v_c:]}}
+    with M.compute_dtype(torch.float32):
+        img, x0 = pipe.sample(batch, x_T=x_T, encode_noise=enc_noise, step_noise=z.cuda())
+    e = rel_err(x0.cpu(), want)
+    print(f"DDPM 5-step ancestral sample, f32: latent rel-err {e:.3e}")
+    assert e < 1e-3 and torch.isfinite(img).all() and img.shape == (b, v_t, 3, res, res)
+    # a different draw gives a different sample (the noise really enters)
+    with M.compute_dtype(torch.float32):
+        _, x1 = pipe.sample(batch, x_T=x_T, encode_noise=enc_noise, step_generator=torch.Generator(device="cuda").manual_seed(1), decode=False)
+    assert rel_err(x1.cpu(), want) > 1e-2
+
+
 # ------------------------------------------------------------------------------------------------ VAE vs oracle
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_vae_decode_encode_vs_oracle(M, dtype):

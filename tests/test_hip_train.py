@@ -180,7 +180,7 @@ def test_ema_follows_torch_averaged_model(golden):
     """`model.ema` (diffusion_wrapper.py:138-142,152-154): the fused flat-buffer EMA against torch's own
     `AveragedModel(denoiser, multi_avg_fn=get_ema_multi_avg_fn(0.995)).update_parameters(denoiser)`, called where Lightning calls
     `on_before_zero_grad` -- at the start of every accumulation window -- over three optimizer steps of the HIP trainer: the
-    averaged parameters agree bit for bit (same lerp arithmetic), the first update is a copy, and sampling `with ema.applied()`
+    averaged parameters agree to the last bit or two (same lerp arithmetic), the first update is a copy, and sampling `with ema.applied()`
     runs the averaged weights and restores the live ones."""
     import copy
     from torch.optim.swa_utils import AveragedModel, get_ema_multi_avg_fn
@@ -201,7 +201,8 @@ def test_ema_follows_torch_averaged_model(golden):
         want = ref.state_dict()
         assert set(got) == set(want), set(got) ^ set(want)
         for k, v in want.items():
-            assert torch.equal(got[k].cpu(), v), (step, k, float((got[k].cpu() - v).abs().max()))
+            # (ATen's CPU lerp uses a fused multiply-add in its vector loop and separate operations in the scalar tail: 1 ulp)
+            assert float((got[k].cpu() - v).abs().max()) <= 2.4e-7 * max(float(v.abs().max()), 1e-30), (step, k, float((got[k].cpu() - v).abs().max()))
     assert tr.global_step == 3
     # the average lags: it has seen theta_0 (copy), theta_1, theta_2 -- not the weights after the third step
     name = "unet.conv_out.bias"
