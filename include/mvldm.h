@@ -348,7 +348,13 @@ enum {
     MVLDM_OP_ELTWISE, MVLDM_OP_DDIM_STEP, MVLDM_OP_DDIM_ADVANCE, MVLDM_OP_NCHW_TO_NHWC, MVLDM_OP_NHWC_TO_NCHW,
     MVLDM_OP_MEMCPY, MVLDM_OP_RAY_ENCODE, MVLDM_OP_POSTERIOR_SAMPLE,
     MVLDM_OP_WGRAD, MVLDM_OP_ATTENTION_BWD, MVLDM_OP_GROUPNORM_BWD, MVLDM_OP_LAYERNORM_BWD, MVLDM_OP_COLSUM,
-    MVLDM_OP_TRAIN_ELTWISE, MVLDM_OP_POOL2X2, MVLDM_OP_ZERO_INSERT, MVLDM_OP_ADD_NOISE, MVLDM_OP_MSE_LOSS, MVLDM_OP_FILL_ZERO
+    MVLDM_OP_TRAIN_ELTWISE, MVLDM_OP_POOL2X2, MVLDM_OP_ZERO_INSERT, MVLDM_OP_ADD_NOISE, MVLDM_OP_MSE_LOSS, MVLDM_OP_FILL_ZERO,
+    /* markers (no payload): the ops between PAR_BEGIN and PAR_END form lanes separated by PAR_NEXT; the caller declares the lanes
+     * mutually independent (disjoint outputs and workspaces).  mvldm_plan_run / _capture put lane 0 on the caller's stream and the
+     * others on the plan's own side streams, forked and joined with events -- under capture these become parallel branches of the
+     * hipGraph (the four sub-pixel phase convs of an upsampler, a resnet's 1x1 shortcut beside its main chain: what fills the chip at
+     * one or two scenes).  mvldm_op_run and mvldm_plan_profile treat them as no-ops (serial order is always valid). */
+    MVLDM_OP_PAR_BEGIN, MVLDM_OP_PAR_NEXT, MVLDM_OP_PAR_END
 };
 
 typedef struct mvldm_op {

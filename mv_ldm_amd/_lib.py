@@ -21,7 +21,7 @@ GN_MAX_CHUNKS = 32
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_TIMESTEP_EMBED, OP_ELTWISE, OP_DDIM_STEP, OP_DDIM_ADVANCE,
  OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY, OP_RAY_ENCODE, OP_POSTERIOR_SAMPLE,
  OP_WGRAD, OP_ATTENTION_BWD, OP_GROUPNORM_BWD, OP_LAYERNORM_BWD, OP_COLSUM, OP_TRAIN_ELTWISE, OP_POOL2X2, OP_ZERO_INSERT,
- OP_ADD_NOISE, OP_MSE_LOSS, OP_FILL_ZERO) = range(1, 25)
+ OP_ADD_NOISE, OP_MSE_LOSS, OP_FILL_ZERO, OP_PAR_BEGIN, OP_PAR_NEXT, OP_PAR_END) = range(1, 28)
 TE_SILU_BWD, TE_ADD, TE_GEGLU_FWD, TE_GEGLU_BWD, TE_GELU_BWD = 0, 1, 2, 3, 4
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t

@@ -146,6 +146,9 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
             MVLDM_CHECK_HIP(hipMemcpyAsync(m.dst, m.src, m.bytes, hipMemcpyDeviceToDevice, s));
             return MVLDM_OK;
         }
+        case MVLDM_OP_PAR_BEGIN:
+        case MVLDM_OP_PAR_NEXT:
+        case MVLDM_OP_PAR_END: return MVLDM_OK;      // lane markers: serial execution is always valid
         default: return set_error(MVLDM_ERR_ARG, "plan: unknown op kind %d", op.kind);
     }
 }
@@ -155,7 +158,24 @@ struct mvldm_plan {
     std::vector<mvldm_op> ops;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // parallel lanes (MVLDM_OP_PAR_*): side streams and the fork / join events, created on first use
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> join;
+    hipEvent_t fork = nullptr;
 };
+
+static int ensure_lane(mvldm_plan* p, int lane) {      // lane >= 1 -> p->side[lane - 1]
+    if (!p->fork) MVLDM_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+    while ((int)p->side.size() < lane) {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        MVLDM_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        MVLDM_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        p->side.push_back(st);
+        p->join.push_back(ev);
+    }
+    return MVLDM_OK;
+}
 
 using namespace mvldm;
 
@@ -176,10 +196,44 @@ extern "C" int mvldm_plan_num_ops(const mvldm_plan* p) { return p ? (int)p->ops.
 
 extern "C" int mvldm_plan_run_range(mvldm_plan* p, int first, int last, mvldm_stream_t stream) {
     MVLDM_REQUIRE(p && first >= 0 && last <= (int)p->ops.size() && first <= last, "plan_run_range: bad range");
+    hipStream_t s = (hipStream_t)stream, cur = s;
+    static const bool serial = getenv("MVLDM_PLAN_SERIAL") && atoi(getenv("MVLDM_PLAN_SERIAL"));      // A/B knob: ignore the lane markers
+    bool in_group = false;
+    int lane = 0;
     for (int i = first; i < last; ++i) {
-        int rc = run_op(p->ops[i], (hipStream_t)stream);
-        if (rc) return rc;
+        const mvldm_op& op = p->ops[i];
+        if (!serial && op.kind == MVLDM_OP_PAR_BEGIN) {
+            MVLDM_REQUIRE(!in_group, "plan: nested parallel group at op %d", i);
+            if (int rc = ensure_lane(p, 0)) return rc;
+            MVLDM_CHECK_HIP(hipEventRecord(p->fork, s));
+            in_group = true;
+            lane = 0;
+            cur = s;
+        } else if (!serial && op.kind == MVLDM_OP_PAR_NEXT) {
+            MVLDM_REQUIRE(in_group, "plan: the range [%d, %d) starts inside a parallel group", first, last);
+            ++lane;
+            if (int rc = ensure_lane(p, lane)) return rc;
+            cur = p->side[lane - 1];
+            MVLDM_CHECK_HIP(hipStreamWaitEvent(cur, p->fork, 0));
+        } else if (!serial && op.kind == MVLDM_OP_PAR_END) {
+            MVLDM_REQUIRE(in_group, "plan: the range [%d, %d) starts inside a parallel group", first, last);
+            for (int l = 1; l <= lane; ++l) {
+                MVLDM_CHECK_HIP(hipEventRecord(p->join[l - 1], p->side[l - 1]));
+                MVLDM_CHECK_HIP(hipStreamWaitEvent(s, p->join[l - 1], 0));
+            }
+            in_group = false;
+            cur = s;
+        } else {
+            int rc = run_op(op, cur);
+            if (rc) {
+                if (in_group)      // leave no side stream dangling (a capture in progress must still be joinable)
+                    for (int l = 1; l <= lane; ++l)
+                        if (hipEventRecord(p->join[l - 1], p->side[l - 1]) == hipSuccess) (void)hipStreamWaitEvent(s, p->join[l - 1], 0);
+                return rc;
+            }
+        }
     }
+    MVLDM_REQUIRE(!in_group, "plan: the range [%d, %d) ends inside a parallel group", first, last);
     return MVLDM_OK;
 }
 
@@ -244,5 +298,8 @@ extern "C" void mvldm_plan_destroy(mvldm_plan* p) {
     if (!p) return;
     if (p->exec) hipGraphExecDestroy(p->exec);
     if (p->graph) hipGraphDestroy(p->graph);
+    for (hipStream_t st : p->side) hipStreamDestroy(st);
+    for (hipEvent_t ev : p->join) hipEventDestroy(ev);
+    if (p->fork) hipEventDestroy(p->fork);
     delete p;
 }

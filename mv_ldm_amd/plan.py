@@ -43,6 +43,9 @@ class Builder:
         self._ws_bytes = splitk_ws_bytes
         self._gn_ws = None
         self._scope: List[str] = []
+        self._lane = 0                  # > 0 inside a parallel group (`parallel()`): which lane the next ops belong to
+        self._lane_ws: dict = {}        # lane -> its own split-K / GroupNorm workspaces (lanes run concurrently)
+        self._deferred: Optional[list] = None
 
     # ---- memory ---------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None) -> torch.Tensor:
@@ -65,9 +68,56 @@ class Builder:
         if t is None or not self.record:
             return
         base = t.reshape(-1).view(torch.uint8)
+        if self._deferred is not None:      # inside a parallel group another lane could pick the buffer up while this lane's
+            self._deferred.append(base)     # op is still running: hand it back when the lanes have joined
+            return
         self._pool.setdefault(base.numel(), []).append(base)
 
+    # ---- parallel lanes -------------------------------------------------------------------------
+    class _Parallel:
+        """`with b.parallel() as par:` -- the ops emitted after each `par.lane()` form one lane; the lanes are declared mutually
+        independent (MVLDM_OP_PAR_* markers: side streams / parallel hipGraph branches in the C executor).  Lanes get their own
+        split-K / GroupNorm workspaces and temporaries freed inside the group return to the pool only after the join."""
+
+        def __init__(self, b):
+            self.b, self.n = b, 0
+
+        def __enter__(self):
+            assert self.b._deferred is None, "parallel groups do not nest"
+            self.b._marker(L.OP_PAR_BEGIN, "par_begin")
+            self.b._deferred = []
+            return self
+
+        def lane(self):
+            if self.n:
+                self.b._marker(L.OP_PAR_NEXT, "par_next")
+            self.b._lane = self.n
+            self.n += 1
+
+        def __exit__(self, *a):
+            b = self.b
+            b._marker(L.OP_PAR_END, "par_end")
+            b._lane = 0
+            deferred, b._deferred = b._deferred, None
+            for base in deferred:
+                b._pool.setdefault(base.numel(), []).append(base)
+
+    def parallel(self):
+        return Builder._Parallel(self)
+
+    def _marker(self, kind: int, name: str):
+        op = L.Op()
+        op.kind = kind
+        self._emit(op, name)
+
     def splitk_ws(self) -> torch.Tensor:
+        if self._lane:
+            ws = self._lane_ws.get(("splitk", self._lane))
+            if ws is None:
+                ws = torch.empty(min(self._ws_bytes, 64 << 20), dtype=torch.uint8, device=self.device)
+                self._lane_ws[("splitk", self._lane)] = ws
+                self.keep.append(ws)
+            return ws
         if self._ws is None:
             self._ws = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
             self.keep.append(self._ws)
@@ -75,6 +125,13 @@ class Builder:
 
     def gn_ws(self, n_img: int, groups: int) -> torch.Tensor:
         need = n_img * L.GN_MAX_CHUNKS * groups * 16
+        if self._lane:
+            ws = self._lane_ws.get(("gn", self._lane))
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
+                self._lane_ws[("gn", self._lane)] = ws
+                self.keep.append(ws)
+            return ws
         if self._gn_ws is None or self._gn_ws.numel() < need:
             self._gn_ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=self.device)
             self.keep.append(self._gn_ws)
@@ -152,36 +209,58 @@ class Builder:
         self._emit(op, name, 2.0 * m * pw.n_out * k_real, nbytes, (x, x2, pw.data, bias, row_bias, residual, out))
         return out
 
+    def small_launch(self, rows: int, n_out: int) -> bool:
+        """should independent launches of this size run as parallel lanes?  OFF by default (MVLDM_PAR_ROWS=0): measured on MI355X /
+        ROCm 7 the fork + join of a two-to-four-branch section of a hipGraph costs ~80 us, more than the lanes save -- with the
+        3 upsamplers' phase convs and the 14 shortcut convs as lanes (MVLDM_PAR_ROWS=16384: launches of <= 16384 rows x 640 columns)
+        one DDIM step at 1 scene went 6.10 -> 7.1 ms, at 4 scenes 12.2 -> 12.9 (profiles/r03_parallel_lanes.txt).  The executor
+        support and the builder API stay (correct, tested); the threshold is what a runtime with cheaper graph edges would set."""
+        limit = int(os.environ.get("MVLDM_PAR_ROWS", "0"))
+        return self.record and rows * max(n_out, 1) <= limit * 640 and limit > 0
+
     def conv_upsample_phases(self, x, pws, bias=None, name="upsample"):
         """nearest-2x + 3x3 conv as four 2x2 phase convs on the low-resolution input (ops.upsample_phase_weights)"""
         n, h, w, c0 = x.shape
         out = self.empty(n, 2 * h, 2 * w, pws[0].n_out, dtype=x.dtype)
-        ws = self.splitk_ws()        # small batches: K = 4C is long and there are few output tiles -- let the library split K
+        # the four phases write disjoint pixels of `out`: at a few scenes one phase is far from filling the chip (b = 1: 36 us each
+        # at 210 TFLOP/s) and they run as parallel lanes; big launches gain nothing from sharing the CUs and stay serial
+        lanes = self.parallel() if self.small_launch(n * h * w, pws[0].n_out) else None
+        if lanes is not None:
+            lanes.__enter__()
         for phase, pw in enumerate(pws):
-            assert pw.ksize == 2 and pw.k_order == 1 and c0 == pw.c_pad
-            op = L.Op()
-            op.kind = L.OP_IGEMM
-            d = op.u.igemm
-            d.src0, d.src1, d.weight = ptr(x), None, ptr(pw.data)
-            d.bias, d.row_bias, d.residual, d.dst = ptr(bias), None, None, ptr(out)
-            d.c0, d.c1 = c0, 0
-            d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, h, w
-            d.ksize, d.stride, d.pad, d.upsample = 2, 1, 0, 2 + phase
-            d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
-            d.row_bias_ld = 0
-            d.epilogue, d.act_dtype, d.dst_dtype = L.EPI_NONE, dt(x), dt(out)
-            d.splitk, d.tile, d.out_scale = 0, 0, 1.0
-            d.dst_ld = 0
-            d.k_order = 1
-            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-            m = n * h * w
-            es = x.element_size()
-            nbytes = (pw.n_out * 4 * c0 + (m * c0 if phase == 0 else 0)) * es + m * pw.n_out * es
-            if self.record:
-                own = self.__dict__.get("_own_ptrs", ())
-                self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = (x if x.data_ptr() in own else None, None)
-            self._emit(op, f"{name}.p{phase}", 2.0 * m * pw.n_out * 4 * c0, nbytes, (x, pw.data, bias, out))
+            if lanes is not None:
+                lanes.lane()
+            self._phase_conv(x, pw, bias, out, phase, name)
+        if lanes is not None:
+            lanes.__exit__(None, None, None)
         return out
+
+    def _phase_conv(self, x, pw, bias, out, phase, name):
+        n, h, w, c0 = x.shape
+        ws = self.splitk_ws()        # small batches: K = 4C is long and there are few output tiles -- let the library split K
+        assert pw.ksize == 2 and pw.k_order == 1 and c0 == pw.c_pad
+        op = L.Op()
+        op.kind = L.OP_IGEMM
+        d = op.u.igemm
+        d.src0, d.src1, d.weight = ptr(x), None, ptr(pw.data)
+        d.bias, d.row_bias, d.residual, d.dst = ptr(bias), None, None, ptr(out)
+        d.c0, d.c1 = c0, 0
+        d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, h, w
+        d.ksize, d.stride, d.pad, d.upsample = 2, 1, 0, 2 + phase
+        d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
+        d.row_bias_ld = 0
+        d.epilogue, d.act_dtype, d.dst_dtype = L.EPI_NONE, dt(x), dt(out)
+        d.splitk, d.tile, d.out_scale = 0, 0, 1.0
+        d.dst_ld = 0
+        d.k_order = 1
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        m = n * h * w
+        es = x.element_size()
+        nbytes = (pw.n_out * 4 * c0 + (m * c0 if phase == 0 else 0)) * es + m * pw.n_out * es
+        if self.record:
+            own = self.__dict__.get("_own_ptrs", ())
+            self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = (x if x.data_ptr() in own else None, None)
+        self._emit(op, f"{name}.p{phase}", 2.0 * m * pw.n_out * 4 * c0, nbytes, (x, pw.data, bias, out))
 
     def linear(self, x, pw: PackedWeight, bias=None, *, residual=None, epilogue=L.EPI_NONE, out_dtype=None, out=None,
                name="linear", row_bias=None):

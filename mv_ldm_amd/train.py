@@ -105,6 +105,10 @@ class TrainBuilder(Builder):
         self.touched: set = set()
         self.grad_writes: List[Tuple[int, int, int]] = []      # (op index, flat offset, numel) of every parameter-gradient write
         self._wws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)      # wgrad slabs / colsum / norm partials
+
+    def small_launch(self, rows: int, n_out: int) -> bool:
+        """training plans are run in segments between collectives and replay their tape in reverse: no parallel lanes"""
+        return False
         self.keep.append(self._wws)
 
     def free(self, t):      # every activation is kept for the backward pass

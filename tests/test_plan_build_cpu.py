@@ -98,3 +98,78 @@ def test_vae_decoder_plan(cpu_record):
     z = v.encoder.emit(b2, torch.zeros(1, 256, 256, 8, dtype=torch.bfloat16))
     assert z.shape == (1, 32, 32, 8)
     assert abs(sum(mm.flops for mm in b2.meta) / 0.273e12 - 1) < 0.06
+
+
+def test_parallel_lanes_only_at_small_batches(cpu_record, monkeypatch):
+    """MVLDM_OP_PAR_* markers (opt-in, MVLDM_PAR_ROWS): at one scene (9 images, 32x32 latents) the four phase convs of every upsampler and the 1x1
+    shortcut of a resnet beside its norm1 -> conv1 -> norm2 chain are emitted as parallel lanes -- well-formed groups, the
+    shortcut's lane holds exactly one op, lanes own their split-K workspaces -- and at 64 scenes no marker is emitted at all"""
+    _, b_off, _ = build_unet_plan(9, [5, 4], 32)
+    assert not any(mm.kind == L.OP_PAR_BEGIN for mm in b_off.meta)      # default: off (measured slower, plan.Builder.small_launch)
+    monkeypatch.setenv("MVLDM_PAR_ROWS", "16384")
+    _, b, _ = build_unet_plan(9, [5, 4], 32)
+    kinds = [mm.kind for mm in b.meta]
+    names = [mm.name for mm in b.meta]
+    n_begin, n_end = kinds.count(L.OP_PAR_BEGIN), kinds.count(L.OP_PAR_END)
+    assert n_begin == n_end == 3 + 14, (n_begin, n_end)       # 3 upsamplers + the 14 resnets that have a conv_shortcut
+    depth, lanes, groups = 0, 0, []
+    for k, n in zip(kinds, names):
+        if k == L.OP_PAR_BEGIN:
+            assert depth == 0
+            depth, lanes, cur = 1, 1, [[]]
+        elif k == L.OP_PAR_NEXT:
+            assert depth == 1
+            lanes += 1
+            cur.append([])
+        elif k == L.OP_PAR_END:
+            assert depth == 1
+            depth = 0
+            groups.append(cur)
+        elif depth:
+            cur[-1].append(n)
+    assert depth == 0
+    up = [g for g in groups if len(g) == 4]
+    sc = [g for g in groups if len(g) == 2]
+    assert len(up) == 3 and all(len(lane) == 1 and f".p{i}" in lane[0] for g in up for i, lane in enumerate(g))
+    assert len(sc) == 14 and all(len(g[1]) == 1 and g[1][0].endswith("conv_shortcut") for g in sc)
+    assert all([n.rsplit("/", 1)[-1] for n in g[0] if "reduce" not in n][:3] == ["norm1+silu", "conv1", "norm2+silu"] for g in sc)
+    # lanes > 0 use their own split-K workspace
+    ws = {}
+    lane = 0
+    for op, k in zip(b.ops, kinds):
+        if k == L.OP_PAR_BEGIN:
+            lane = 0
+        elif k == L.OP_PAR_NEXT:
+            lane += 1
+        elif k == L.OP_PAR_END:
+            lane = 0
+        elif k == L.OP_IGEMM and op.u.igemm.workspace:
+            ws.setdefault(lane, set()).add(op.u.igemm.workspace)
+    assert all(len(v) == 1 for v in ws.values()) and len({next(iter(v)) for v in ws.values()}) == len(ws) >= 4
+    p = b.finalize()
+    assert len(p) == len(names)
+    # 8 scenes: only the 8x8 / 4x4 levels are still small; 64 scenes: nothing is
+    _, b8, _ = build_unet_plan(9 * 8, [5] * 8 + [4] * 8, 32)
+    in_group = False
+    for mm in b8.meta:
+        in_group = mm.kind == L.OP_PAR_BEGIN or (in_group and mm.kind != L.OP_PAR_END)
+        if in_group and mm.kind == L.OP_IGEMM:
+            assert any(lvl in mm.name for lvl in ("down2", "down3", "mid", "up0", "up1")), mm.name
+    _, b64, _ = build_unet_plan(9 * 64, [5] * 64 + [4] * 64, 32)
+    assert not any(mm.kind in (L.OP_PAR_BEGIN, L.OP_PAR_NEXT, L.OP_PAR_END) for mm in b64.meta)
+    monkeypatch.setenv("MVLDM_PAR_ROWS", "0")
+    _, b0, _ = build_unet_plan(9, [5, 4], 32)
+    assert not any(mm.kind == L.OP_PAR_BEGIN for mm in b0.meta)
+
+
+def test_temporaries_freed_inside_a_parallel_group_wait_for_the_join(cpu_record):
+    b = plan.Builder("cpu", torch.bfloat16, record=True, splitk_ws_bytes=1 << 20)
+    a = b.empty(4, 8)
+    with b.parallel() as par:
+        par.lane()
+        b.free(a)
+        par.lane()
+        c = b.empty(4, 8)                  # must NOT be handed the buffer lane 0 just released
+        assert c.data_ptr() != a.data_ptr()
+    d = b.empty(4, 8)                      # after the join it is free again
+    assert d.data_ptr() == a.data_ptr()
