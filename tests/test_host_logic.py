@@ -48,8 +48,10 @@ def test_scheduler_tables_bit_exact(golden):
     assert set(SCHEDULER) == {"ddim", "ddpm"}                    # src/model/scheduler/__init__.py:19-22
     p = SCHEDULER["ddpm"](clip_sample=False)
     assert np.array_equal(p.add_noise(x, e, torch.tensor([10, 900])).numpy(), g["kat_add_noise"])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):    # the ancestral step is a HIP kernel (tests/test_hip_ops.py)
         p.step(e, 10, x)
+    with pytest.raises(NotImplementedError):
+        SCHEDULER["ddpm"](variance_type="learned")
 
 
 def test_scheduler_from_pretrained_reads_a_local_snapshot(tmp_path):
