@@ -257,7 +257,9 @@ typedef struct mvldm_wgrad_desc {
     int32_t ksize, stride, pad, upsample;      /* upsample: 0 | 1 (nearest-2x gather in front of a 3x3 conv) */
     int32_t n_out, dy_ld;
     int32_t act_dtype;
-    int32_t accumulate;                        /* 0: grad = ...; 1: grad += ... (gradient accumulation over micro-batches) */
+    int32_t accumulate;                        /* bit 0: 0 grad = ..., 1 grad += ... (accumulation over micro-batches);
+                                                * bits 8-9: kernel form, 0 = the library's rule, 1 = register-staged [128 n x 64 c] tile,
+                                                * 2 = wide LDS-DMA [320 n x 128 c] tile (refused where it does not apply) */
 } mvldm_wgrad_desc;
 int mvldm_igemm_wgrad(const mvldm_wgrad_desc* d, mvldm_stream_t stream);
 

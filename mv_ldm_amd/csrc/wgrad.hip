@@ -29,10 +29,41 @@ struct WgradParams {
     int M, n_out, dy_ld;
     int tiles_n, tiles_c;           // grid.x = tiles_n * taps * tiles_c
     int rows_per_split;             // pixels per split (multiple of 64)
+    int n_tiles, n_splits;          // 1-D grid of 8 * ceil(n_splits / 8) * n_tiles workgroups (wg_map)
+    int xcd_map;                    // 0: tile fastest, split slowest (hardware round-robin over the XCDs)
     int kdim;                       // taps * ctot (row length of a slab)
 };
 
 constexpr int WG_BN = 128, WG_BC = 64, WG_BP = 64;
+
+// workgroup -> (tile, split).  Default: tile fastest -- the tiles of a split (which walk the SAME pixel rows: dY rows for every
+// tap and channel tile, X rows shifted by the tap) are dealt round-robin over the 8 XCDs and run at the same time, so a row
+// comes out of HBM once and is handed to the eight L2s by the memory-side cache.  MVLDM_WGRAD_XCD=1 keeps a split on ONE XCD
+// instead (split = 8 * group + b mod 8; fewer than 8 splits: split s owns the XCDs {x : x mod n_splits == s}): 4-7 % faster when the
+// operands are already cache-resident (tools/wgrad_bench.py repeats one launch), 3-7 % SLOWER inside the training plan, where
+// they come from HBM (wgrad total 17.6 -> 18.2 ms) -- measured, left off.
+__device__ __forceinline__ bool wg_map(const WgradParams& p, int& tile, int& split) {
+    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+    if (!p.xcd_map) {
+        tile = b % p.n_tiles;
+        split = b / p.n_tiles;
+        return split < p.n_splits;
+    }
+    if (p.n_splits >= 8) {
+        tile = i % p.n_tiles;
+        split = (i / p.n_tiles) * 8 + xcd;
+        return split < p.n_splits;
+    }
+    split = xcd % p.n_splits;
+    const int rank = xcd / p.n_splits, cnt = (8 - split + p.n_splits - 1) / p.n_splits;      // this XCD's rank among the split's XCDs
+    tile = i * cnt + rank;
+    return tile < p.n_tiles;
+}
+static const int kWgXcd = getenv("MVLDM_WGRAD_XCD") ? atoi(getenv("MVLDM_WGRAD_XCD")) : 0;
+static inline int wg_grid(int tiles, int splits) {
+    if (!kWgXcd) return tiles * splits;
+    return splits >= 8 ? 8 * ((splits + 7) / 8) * tiles : 8 * ((tiles + (8 / splits) - 1) / (8 / splits));
+}
 
 template <typename T> struct WgMma;
 template <> struct WgMma<bf16_t> {
@@ -67,11 +98,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    int b = blockIdx.x;
+    int b, split;
+    if (!wg_map(p, b, split)) return;              // uniform per workgroup, before any barrier
     const int tc = b % p.tiles_c; b /= p.tiles_c;
     const int tap = b % p.taps;
     const int tn = b / p.taps;
-    const int split = blockIdx.z;
     const int m_begin = split * p.rows_per_split, m_end = min(p.M, m_begin + p.rows_per_split);
     const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
     const int hs = p.upsample ? 2 * p.h_in : p.h_in, wsz = p.upsample ? 2 * p.w_in : p.w_in;
@@ -181,6 +212,161 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---- 16-bit wide-tile form: LDS-DMA staging, [320 n] x [128 c] per tap and workgroup ----------------------------------
+// The kernel above stages through registers (global -> VGPR -> ds_write_b128, 13 LDS cycles per 1 KB wave store) and owns a
+// [128 n] x [64 c] tile: at 5 workgroups per CU the LDS pipe is busier with the tile WRITES than the matrix cores are with
+// the MFMAs (op table of the training plan: 291 TFLOP/s), and n_out = 320 wastes 17 % of a 3 x 128 tile row.  Here:
+//   * tile [320 n] x [128 c] of one tap, 8 waves, wave tile [160 n] x [32 c] (5 accumulator blocks): every channel count of
+//     this UNet is a multiple of 320 on the n side; 93 flop per staged byte (was 43); 12 transpose reads per 5 MFMAs (was 3 per 1);
+//   * both operand tiles go global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write) into a 2-slot
+//     ring, one barrier per 64-pixel step; rows past the split's range, columns past n_out / c_tot and out-of-image taps use
+//     an out-of-range buffer offset, which the descriptor's range check turns into zeros;
+//   * row pitches 704 B (dY: 640 + 64) and 320 B (X: 256 + 64): the four pixel rows of a transpose-read half-wave land on
+//     the four different 64-byte bank groups; the pad chunks are DMA lanes parked out of range;
+//   * the pixel -> (y, x) split of the 3x3 gather is shifts and masks (the host takes this path for power-of-two maps only).
+// Same slabs / same reduce kernel / same fragment permutation as above: bit-identical sums per split, different split count.
+constexpr int WD_BN = 320, WD_BC = 128;
+constexpr int WD_DP = 704, WD_XP = 320;                         // row pitches (bytes): one pixel row of both tiles = 1 KB = one DMA piece
+constexpr int WD_RING = 128 * 1024;                             // LDS ring: BP pixels per slot, 128 / BP slots
+static_assert(WD_DP + WD_XP == 1024, "a pixel row of the stage is one 1 KB piece");
+constexpr unsigned kWdOob = 0xFFFFFFF0u;
+
+struct WgradDmaParams {
+    WgradParams w;
+    unsigned x_bytes;               // extent of the activation tensor
+    int lw, lh;                     // log2 of w_out / h_out (3x3 gather)
+};
+
+// issue the BP-pixel tile starting at pixel m0 into the ring slot at `stage`: BP pieces of 1 KB, BP / 8 per wave.  Piece index
+// < BP * 704 / 1024 belongs to the dY region ([BP][704 B]), the rest to the X region ([BP][320 B]) behind it.
+template <typename T, int BP>
+__device__ __forceinline__ void wd_issue(const WgradDmaParams& q, char* stage, int wave, int m0, int m_end, int dy_disp,
+                                         const unsigned (&dv)[BP / 8], const int (&xrow)[BP / 8], const unsigned (&xcol)[BP / 8], int ky, int kx) {
+    constexpr int DQ = BP * WD_DP / 1024;
+    const WgradParams& p = q.w;
+    // dY: the descriptor starts at the tile's first pixel row and ends with the split's range
+    const char* dbase = reinterpret_cast<const char*>(p.dy) + (size_t)m0 * (size_t)p.dy_ld * 2u;
+    const size_t dleft = (size_t)(m_end - m0) * (size_t)p.dy_ld * 2u;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase), 0, dleft > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)dleft, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src0), 0, q.x_bytes, 0x00020000);
+    const int wmask = p.w_out - 1, hmask = p.h_out - 1;
+#pragma unroll
+    for (int j = 0; j < BP / 8; ++j) {
+        const int piece = wave + 8 * j;                            // wave-uniform
+        __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(stage + piece * 1024);
+        if (piece < DQ) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, dst, 16, dv[j], 0, 0, 0);
+        } else {
+            const int m = m0 + xrow[j];
+            bool ok = m < m_end;
+            if (p.ksize == 3) {
+                const int ox = m & wmask, oy = (m >> q.lw) & hmask;
+                ok = ok && (unsigned)(oy + ky - 1) < (unsigned)p.h_out && (unsigned)(ox + kx - 1) < (unsigned)p.w_out;
+            }
+            const unsigned v = (ok && xcol[j] != kWdOob) ? (unsigned)(m + dy_disp) * (unsigned)p.ctot * 2u + xcol[j] : kWdOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, v, 0, 0, 0);
+        }
+    }
+}
+
+template <typename T, int BP>
+__global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradDmaParams q) {
+    static_assert(sizeof(T) == 2, "wide-tile weight gradient: 16-bit activations");
+    static_assert(BP == 64 || BP == 32, "64-pixel slots x 2 or 32-pixel slots x 4");
+    constexpr int STAGE = BP * 1024, NSLOT = WD_RING / STAGE, PW = BP / 8;        // pieces per wave and tile
+    constexpr int DQ = BP * WD_DP / 1024;
+    const WgradParams& p = q.w;
+    extern __shared__ __attribute__((aligned(16))) char wd_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    int b, split;
+    if (!wg_map(p, b, split)) return;              // uniform per workgroup, before any barrier
+    const int tc = b % p.tiles_c; b /= p.tiles_c;
+    const int tap = b % p.taps;
+    const int tn = b / p.taps;
+    const int m_begin = split * p.rows_per_split, m_end = min(p.M, m_begin + p.rows_per_split);
+    const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+    const int disp = p.ksize == 3 ? (ky - 1) * p.w_out + (kx - 1) : 0;
+
+    // per-lane slots of this wave's DMA pieces (fixed over the pixel loop)
+    unsigned dv[PW], xcol[PW];
+    int xrow[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int piece = wave + 8 * j;
+        dv[j] = kWdOob; xcol[j] = kWdOob; xrow[j] = 0;
+        if (piece < DQ) {
+            const int s = piece * 64 + lane, row = s / (WD_DP / 16), ch = s - row * (WD_DP / 16);
+            const int n = tn * WD_BN + ch * 8;
+            if (ch < WD_BN / 8 && n < p.n_out) dv[j] = ((unsigned)row * (unsigned)p.dy_ld + (unsigned)n) * 2u;
+        } else {
+            const int s = (piece - DQ) * 64 + lane, row = s / (WD_XP / 16), ch = s - row * (WD_XP / 16);
+            const int c = tc * WD_BC + ch * 8;
+            xrow[j] = row;
+            if (ch < WD_BC / 8 && c < p.ctot) xcol[j] = (unsigned)c * 2u;
+        }
+    }
+
+    const int wn = wave >> 2, wc = wave & 3;                       // wave tile: n rows [wn*160, +160), c columns [wc*32, +32)
+    f32x16 acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // transpose-read source of this lane (see wgrad_kernel): pixel row 4*(gi>>1) + (sl>>2) (+8), columns (gi&1)*16 + 4*(sl&3) .. +3
+    const int gi = lane >> 4, sl = lane & 15;
+    const int prow = 4 * (gi >> 1) + (sl >> 2), pcol = (gi & 1) * 16 + 4 * (sl & 3);
+    const int d_off = prow * WD_DP + (wn * 160 + pcol) * 2, x_off = BP * WD_DP + prow * WD_XP + (wc * 32 + pcol) * 2;
+
+    // ring: tiles t+1 .. t+NSLOT-1 are in flight while tile t is consumed
+    const int n_tile = (m_end - m_begin + BP - 1) / BP;
+#pragma unroll
+    for (int k = 0; k < NSLOT - 1; ++k)
+        if (k < n_tile) wd_issue<T, BP>(q, wd_smem + k * STAGE, wave, m_begin + k * BP, m_end, disp, dv, xrow, xcol, ky, kx);
+    int slot = 0;
+    for (int t = 0; t < n_tile; ++t) {
+        // this wave's pieces of tile t have landed: at most the (NSLOT - 2) younger tiles may still be in flight
+        const int younger = min(n_tile - 1 - t, NSLOT - 2);
+        if (NSLOT == 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else if (NSLOT == 4 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // ... everyone's have, and tile t-1's slot is no longer read
+        if (t + NSLOT - 1 < n_tile) {
+            const int fill = slot == 0 ? NSLOT - 1 : slot - 1;
+            wd_issue<T, BP>(q, wd_smem + fill * STAGE, wave, m_begin + (t + NSLOT - 1) * BP, m_end, disp, dv, xrow, xcol, ky, kx);
+        }
+        const char* base = wd_smem + slot * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BP / 16; ++ks) {
+            const T* xa = reinterpret_cast<const T*>(base + x_off + ks * 16 * WD_XP);
+            const auto blo = WgMma<T>::tr(xa), bup = WgMma<T>::tr(reinterpret_cast<const T*>(reinterpret_cast<const char*>(xa) + 8 * WD_XP));
+            const typename WgMma<T>::Frag bf = __builtin_shufflevector(blo, bup, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const char* da = base + d_off + ks * 16 * WD_DP + i * 64;
+                const auto alo = WgMma<T>::tr(reinterpret_cast<const T*>(da)), aup = WgMma<T>::tr(reinterpret_cast<const T*>(da + 8 * WD_DP));
+                const typename WgMma<T>::Frag a = __builtin_shufflevector(alo, aup, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[i] = WgMma<T>::mma(a, bf, acc[i]);
+            }
+        }
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    }
+
+    // partial tile -> slab [split][n][tap * ctot + c]
+    float* slab = p.ws + (size_t)split * p.n_out * p.kdim;
+    const int c = tc * WD_BC + wc * 32 + l31;
+    if (c < p.ctot) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = tn * WD_BN + wn * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (n < p.n_out) slab[(size_t)n * p.kdim + tap * p.ctot + c] = acc[i][r];
+            }
+    }
+}
+
 // grad[n][c][tap] (PyTorch [n_out][c_in][k][k]; c < c_in: padding channels are dropped) = / += sum_splits slab[s][n][tap*ctot + c]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ grad, int n_out, int c_in, int ctot,
                                                            int taps, int splits, int accumulate) {
@@ -228,13 +414,107 @@ int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits) {
     return MVLDM_OK;
 }
 
-int wgrad_run(const mvldm_wgrad_desc& d, hipStream_t s) {
-    if (d.n_img == 0 || d.h_out == 0 || d.w_out == 0 || d.n_out == 0) return MVLDM_OK;
+static inline int ilog2_exact(int v) {       // log2 of a power of two, -1 otherwise
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// the wide-tile LDS-DMA form: 16-bit, one source, stride 1, no upsampling, 1x1 or a 3x3 "same" conv over a power-of-two map,
+// enough rows / columns to fill the tile.  Everything else (f32, conv_in, conv_out, downsamplers, skip-concat shortcuts) keeps
+// the register-staged kernel.  MVLDM_WGRAD_WIDE=0 forces the old form (A/B knob).
+static bool wgrad_wide_ok(const mvldm_wgrad_desc& d) {
+    if (d.act_dtype == MVLDM_F32 || d.src1 || d.c1 || d.stride != 1 || d.upsample) return false;
+    if (d.n_out < 160 || d.c0 < 64 || d.c0 % 8 || d.dy_ld % 8) return false;
+    if (d.ksize == 3 && (d.pad != 1 || d.h_in != d.h_out || d.w_in != d.w_out || ilog2_exact(d.w_out) < 0 || ilog2_exact(d.h_out) < 0)) return false;
+    if (d.ksize == 1 && (d.pad != 0 || d.h_in != d.h_out || d.w_in != d.w_out)) return false;
+    const size_t xb = (size_t)d.n_img * d.h_in * d.w_in * d.c0 * 2u;
+    return xb < 0xFFFFFFF0ull;
+}
+
+static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
+    WgradDmaParams q;
+    WgradParams& p = q.w;
+    int splits = 1;
+    int rc = wgrad_plan(d, p, splits);          // argument checks + the common fields
+    if (rc) return rc;
+    p.tiles_n = cdiv_(d.n_out, WD_BN);
+    p.tiles_c = cdiv_(p.ctot, WD_BC);
+    q.x_bytes = (unsigned)((size_t)d.n_img * d.h_in * d.w_in * d.c0 * 2u);
+    q.lw = d.ksize == 3 ? ilog2_exact(d.w_out) : 0;
+    q.lh = d.ksize == 3 ? ilog2_exact(d.h_out) : 0;
+    // one workgroup per CU: whole rounds of 256, at least 4 pixel steps per split
+    static const int kBp = getenv("MVLDM_WGRAD_WIDE_BP") ? atoi(getenv("MVLDM_WGRAD_WIDE_BP")) : 32;      // 32: 4-slot ring, 64: 2-slot
+    const int tiles = p.tiles_n * p.taps * p.tiles_c, blocks = cdiv_(p.M, 64);
+    static const int kTarget = getenv("MVLDM_WGRAD_WIDE_TARGET") ? atoi(getenv("MVLDM_WGRAD_WIDE_TARGET")) : 512;
+    splits = std::max(1, std::min(kTarget / std::max(tiles, 1), std::max(1, blocks / 4)));
+    const size_t slab = (size_t)d.n_out * p.kdim * sizeof(float);
+    while (splits > 1 && (size_t)splits * slab > d.workspace_bytes) --splits;
+    MVLDM_REQUIRE((size_t)splits * slab <= d.workspace_bytes, "wgrad: workspace of %zu bytes too small (need >= %zu)", d.workspace_bytes, slab);
+    p.rows_per_split = cdiv_(blocks, splits) * 64;
+    splits = cdiv_(p.M, p.rows_per_split);
+    p.n_tiles = tiles;
+    p.n_splits = splits;
+    p.xcd_map = kWgXcd;
+    const dim3 grid(wg_grid(tiles, splits));
+    static std::atomic<uint64_t> done_b{0}, done_h{0}, done_b32{0}, done_h32{0};
+    rc = dispatch_dtype(d.act_dtype, [&](auto t) {
+        using T = decltype(t);
+        if constexpr (sizeof(T) == 2) {
+            constexpr bool B16 = std::is_same<T, bf16_t>::value;
+            if (kBp == 64) {
+                auto* kern = wgrad_dma_kernel<T, 64>;
+                if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), WD_RING, B16 ? done_b : done_h)) return rc0;
+                hipLaunchKernelGGL(kern, grid, dim3(512), WD_RING, s, q);
+            } else {
+                auto* kern = wgrad_dma_kernel<T, 32>;
+                if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), WD_RING, B16 ? done_b32 : done_h32)) return rc0;
+                hipLaunchKernelGGL(kern, grid, dim3(512), WD_RING, s, q);
+            }
+            return check_launch();
+        } else {
+            return set_error(MVLDM_ERR_ARG, "wgrad: wide form is 16-bit only");
+        }
+    });
+    if (rc) return rc;
+    const size_t total = (size_t)d.n_out * d.c_in * p.taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, d.workspace, d.grad, d.n_out,
+                       d.c_in, p.ctot, p.taps, splits, d.accumulate);
+    return check_launch();
+}
+
+// which form?  `accumulate` bits 8-9 carry the caller's choice (1 = register-staged, 2 = wide; the host's plan-time selection
+// times both, plan.autotune_wgrad); 0 = the rule below, from tools/wgrad_bench.py at 32 images (profiles/r03_wgrad_forms.txt):
+// the wide form wins on the 3x3 convs with long pixel ranges (level 0: 1.7x) and with short ones (<= 4096 pixels, many tiles),
+// and on Linears with K >= 1024 and few output columns; the 16x16 level and the wide-N Linears stay with the small tile.
+static bool wgrad_pick_wide(const mvldm_wgrad_desc& d) {
+    static const int force = getenv("MVLDM_WGRAD_WIDE") ? atoi(getenv("MVLDM_WGRAD_WIDE")) : -1;      // A/B knob: 0 never, 1 wherever it applies
+    const int form = (d.accumulate >> 8) & 3;
+    if (!wgrad_wide_ok(d)) return false;
+    if (form) return form == 2;
+    if (force >= 0) return force != 0;
+    const long m = (long)d.n_img * d.h_out * d.w_out;
+    if (d.ksize == 3) return m >= 16384 || m <= 4096;
+    return d.c0 >= 1024 && d.n_out <= 640;
+}
+
+int wgrad_run(const mvldm_wgrad_desc& d0, hipStream_t s) {
+    if (d0.n_img == 0 || d0.h_out == 0 || d0.w_out == 0 || d0.n_out == 0) return MVLDM_OK;
+    const int form = (d0.accumulate >> 8) & 3;
+    MVLDM_REQUIRE(form != 2 || wgrad_wide_ok(d0), "wgrad: the wide form does not take this problem");
+    const bool wide = wgrad_pick_wide(d0);
+    mvldm_wgrad_desc d = d0;
+    d.accumulate &= 1;
+    if (wide) return wgrad_run_wide(d, s);
     WgradParams p;
     int splits = 1;
     int rc = wgrad_plan(d, p, splits);
     if (rc) return rc;
-    const dim3 grid(p.tiles_n * p.taps * p.tiles_c, 1, splits);
+    p.n_tiles = p.tiles_n * p.taps * p.tiles_c;
+    p.n_splits = splits;
+    p.xcd_map = kWgXcd;
+    const dim3 grid(wg_grid(p.n_tiles, splits));
     rc = dispatch_dtype(d.act_dtype, [&](auto t) {
         using T = decltype(t);
         hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(256), 0, s, p);

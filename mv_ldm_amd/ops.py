@@ -365,7 +365,7 @@ def ddpm_cfg_step(eps_c, eps_u, x_t, noise, cfg_scale, coef, clip_range: float =
 
 
 # ------------------------------------------------------------------------------------------ training kernels
-def conv_wgrad(x, dy, grad, *, ksize, stride=1, pad=None, upsample=False, x2=None, c_in=None, accumulate=False, n_out=None) -> torch.Tensor:
+def conv_wgrad(x, dy, grad, *, ksize, stride=1, pad=None, upsample=False, x2=None, c_in=None, accumulate=False, n_out=None, form: int = 0) -> torch.Tensor:
     """x (x2): NHWC forward input(s); dy: NHWC / `[m, ld]` upstream gradient (columns [0, n_out)); grad: fp32 PyTorch-layout
     weight gradient `[n_out, c_in, k, k]` / `[n_out, c_in]`, written or accumulated in place."""
     n, h, w, c0 = x.shape
@@ -382,7 +382,8 @@ def conv_wgrad(x, dy, grad, *, ksize, stride=1, pad=None, upsample=False, x2=Non
     d.c0, d.c1, d.c_in = c0, c1, (c0 + c1) if c_in is None else c_in
     d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, ho, wo
     d.ksize, d.stride, d.pad, d.upsample = ksize, stride, pad, int(upsample)
-    d.n_out, d.dy_ld, d.act_dtype, d.accumulate = n_out, dy.stride(-2), dt(x), int(accumulate)
+    # form: 0 = the library's rule, 1 = register-staged small tile, 2 = wide LDS-DMA tile (bits 8-9 of `accumulate`)
+    d.n_out, d.dy_ld, d.act_dtype, d.accumulate = n_out, dy.stride(-2), dt(x), int(accumulate) | (int(form) << 8)
     L.check(L.load().mvldm_igemm_wgrad(C.byref(d), stream()))
     return grad
 

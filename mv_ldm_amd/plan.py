@@ -411,6 +411,7 @@ class Builder:
             autotune = os.environ.get("MVLDM_AUTOTUNE", "1") != "0"
         if autotune and torch.device(self.device).type == "cuda":
             autotune_igemm(self.ops, srcs=self.__dict__.get("_tune_srcs"))
+            autotune_wgrad(self.ops)
         return Plan(self.ops, self.meta, self.keep, self.device)
 
 
@@ -479,6 +480,51 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
             _TUNE_CACHE[key] = best
             timed += 1
         d.tile = best
+    return timed
+
+
+_WGRAD_CACHE = {}
+
+
+def autotune_wgrad(ops, iters: int = 3) -> int:
+    """plan-time choice between the two weight-gradient kernels (csrc/wgrad.hip: register-staged small tile / wide LDS-DMA tile)
+    per problem signature: both are timed on the op's own buffers (scratch at this point; the gradient it writes is zeroed before
+    the first real run) and the winner goes into bits 8-9 of `desc.accumulate`.  Returns the number of problems timed."""
+    lib = L.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timed = 0
+    scratch = None          # the trials write their gradient HERE: the real accumulator may already hold a micro-batch
+    for op in ops:
+        if op.kind != L.OP_WGRAD:
+            continue
+        d = op.u.wgrad
+        if d.act_dtype == L.F32 or (d.accumulate >> 8) & 3:
+            continue
+        key = (d.c0, d.c1, d.n_img, d.h_in, d.w_in, d.h_out, d.w_out, d.ksize, d.stride, d.pad, d.upsample, d.n_out, d.dy_ld, d.act_dtype)
+        best = _WGRAD_CACHE.get(key)
+        if best is None:
+            trial = L.Op()
+            C.memmove(C.byref(trial), C.byref(op), C.sizeof(L.Op))
+            need = d.n_out * d.c_in * d.ksize * d.ksize
+            if scratch is None or scratch.numel() < need:
+                scratch = torch.empty(need, dtype=torch.float32, device=torch.cuda.current_device())
+            trial.u.wgrad.grad = scratch.data_ptr()
+            results = []
+            for form in (1, 2):
+                trial.u.wgrad.accumulate = (d.accumulate & 1) | (form << 8)
+                if lib.mvldm_op_run(C.byref(trial), stream) != 0:      # the wide form does not take this problem
+                    continue
+                e0.record()
+                for _ in range(iters):
+                    lib.mvldm_op_run(C.byref(trial), stream)
+                e1.record()
+                e1.synchronize()
+                results.append((e0.elapsed_time(e1), form))
+            best = min(results)[1] if results else 0
+            _WGRAD_CACHE[key] = best
+            timed += 1
+        d.accumulate = (d.accumulate & 1) | (best << 8)
     return timed
 
 

@@ -383,6 +383,40 @@ def test_conv_gradients_at_production_shapes(ops, case, dtype):
     assert torch.equal(again, first)            # deterministic reduction order
 
 
+WIDE_CASES = [  # name, ksize, n_img, h, c_in, n_out: ragged n / c tiles, several splits, one split, borders of every tap
+    ("conv320_at32", 3, 4, 32, 320, 320), ("conv_192to160_at16", 3, 3, 16, 192, 160), ("conv_64to480_at8", 3, 5, 8, 64, 480),
+    ("conv1280_at4", 3, 2, 4, 1280, 1280), ("linear_1280to320", 1, 2, 32, 1280, 320), ("linear_72to200", 1, 1, 16, 72, 200)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_wide_weight_gradient_form(ops, case, dtype):
+    """the wide LDS-DMA weight-gradient kernel ([320 n] x [128 c] tile, form 2) against fp64 autograd and against the
+    register-staged kernel (form 1): same products, same fp32 accumulation per split -- only the split count differs"""
+    _, k, n, h, ci, co = case
+    x, w = rnd((n, ci, h, h), 201, dtype), rnd((co, ci, k, k), 202, torch.float32, 1 / math.sqrt(ci * k * k))
+    wd = w.to(dtype).double().requires_grad_()
+    y = F.conv2d(x.double(), wd, None, 1, k // 2)
+    dy = rnd(tuple(y.shape), 203, dtype)
+    gw, = torch.autograd.grad(y, (wd,), dy.double())
+    xa, dyd = nhwc(x, dtype), nhwc(dy, dtype)
+    shape = (co, ci, k, k) if k == 3 else (co, ci)
+    g2 = torch.zeros(shape, device="cuda")
+    ops.conv_wgrad(xa, dyd, g2, ksize=k, form=2)
+    assert relerr(g2.view_as(gw), gw) < TOL[dtype]
+    g1 = torch.zeros(shape, device="cuda")
+    ops.conv_wgrad(xa, dyd, g1, ksize=k, form=1)
+    assert relerr(g2, g1.double().cpu()) < 1e-5
+    ops.conv_wgrad(xa, dyd, g2, ksize=k, form=2, accumulate=True)
+    assert relerr(g2.view_as(gw), 2 * gw) < TOL[dtype]
+    # what the wide form does not take is refused when asked for explicitly, never silently replaced
+    with pytest.raises(RuntimeError, match="wide form"):
+        if k == 3:
+            ops.conv_wgrad(xa, dyd, torch.zeros(shape, device="cuda"), ksize=3, stride=2, form=2)          # a downsampler
+        else:
+            ops.conv_wgrad(xa, dyd, torch.zeros(co, 2 * ci, device="cuda"), ksize=1, x2=xa, form=2)       # a skip-concat shortcut
+
+
 BIG_ATTN = [("d40_3d_5120_4096", 8, 40, [5120, 4096]), ("d64_sd_1024x16", 5, 64, [1024] * 16)]
 
 
