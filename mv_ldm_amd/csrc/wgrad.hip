@@ -272,8 +272,8 @@ __device__ __forceinline__ void wd_issue(const WgradDmaParams& q, char* stage, i
 template <typename T, int BP>
 __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradDmaParams q) {
     static_assert(sizeof(T) == 2, "wide-tile weight gradient: 16-bit activations");
-    static_assert(BP == 64 || BP == 32, "64-pixel slots x 2 or 32-pixel slots x 4");
-    constexpr int STAGE = BP * 1024, NSLOT = WD_RING / STAGE, PW = BP / 8;        // pieces per wave and tile
+    static_assert(BP == 64 || BP == 48 || BP == 32, "64-pixel slots x 2, 48 x 3 or 32 x 4");
+    constexpr int STAGE = BP * 1024, NSLOT = BP == 48 ? 3 : WD_RING / STAGE, PW = BP / 8;        // pieces per wave and tile
     constexpr int DQ = BP * WD_DP / 1024;
     const WgradParams& p = q.w;
     extern __shared__ __attribute__((aligned(16))) char wd_smem[];
@@ -319,38 +319,71 @@ __global__ __launch_bounds__(512) void wgrad_dma_kernel(const WgradDmaParams q) 
     const int prow = 4 * (gi >> 1) + (sl >> 2), pcol = (gi & 1) * 16 + 4 * (sl & 3);
     const int d_off = prow * WD_DP + (wn * 160 + pcol) * 2, x_off = BP * WD_DP + prow * WD_XP + (wc * 32 + pcol) * 2;
 
-    // ring: tiles t+1 .. t+NSLOT-1 are in flight while tile t is consumed
+    // ring: tiles t+1 .. t+NSLOT-1 are in flight while tile t is consumed.  Fragments are double-buffered (fa / fb): the last
+    // 16-pixel group of tile t is multiplied AFTER the barrier that publishes tile t+1, under the DMA issue of tile t+NSLOT and
+    // the LDS latency of tile t+1's first fragments (the igemm loop's arrangement: one wave covers the latency by itself).
+    using Frag = typename WgMma<T>::Frag;
+    struct Frags { Frag a[5], b; };
+    auto load_frags = [&](Frags& f, const char* base, int ks) __attribute__((always_inline)) {
+        const char* xa = base + x_off + ks * 16 * WD_XP;
+        const auto blo = WgMma<T>::tr(reinterpret_cast<const T*>(xa)), bup = WgMma<T>::tr(reinterpret_cast<const T*>(xa + 8 * WD_XP));
+        f.b = __builtin_shufflevector(blo, bup, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const char* da = base + d_off + ks * 16 * WD_DP + i * 64;
+            const auto alo = WgMma<T>::tr(reinterpret_cast<const T*>(da)), aup = WgMma<T>::tr(reinterpret_cast<const T*>(da + 8 * WD_DP));
+            f.a[i] = __builtin_shufflevector(alo, aup, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = WgMma<T>::mma(f.a[i], f.b, acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int NKS = BP / 16;
     const int n_tile = (m_end - m_begin + BP - 1) / BP;
 #pragma unroll
     for (int k = 0; k < NSLOT - 1; ++k)
         if (k < n_tile) wd_issue<T, BP>(q, wd_smem + k * STAGE, wave, m_begin + k * BP, m_end, disp, dv, xrow, xcol, ky, kx);
+    Frags fa, fb;
+    if (n_tile > 0) {
+        // tile 0 has landed (the NSLOT - 2 younger ones may still be in flight)
+        if (NSLOT == 4 && n_tile > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else if (NSLOT >= 3 && n_tile > 1 && !(NSLOT == 4 && n_tile > 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (NSLOT - 1 < n_tile) wd_issue<T, BP>(q, wd_smem + (NSLOT - 1) * STAGE, wave, m_begin + (NSLOT - 1) * BP, m_end, disp, dv, xrow, xcol, ky, kx);
+        load_frags(fa, wd_smem, 0);
+    }
     int slot = 0;
     for (int t = 0; t < n_tile; ++t) {
-        // this wave's pieces of tile t have landed: at most the (NSLOT - 2) younger tiles may still be in flight
-        const int younger = min(n_tile - 1 - t, NSLOT - 2);
-        if (NSLOT == 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
-        else if (NSLOT == 4 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // ... everyone's have, and tile t-1's slot is no longer read
-        if (t + NSLOT - 1 < n_tile) {
-            const int fill = slot == 0 ? NSLOT - 1 : slot - 1;
-            wd_issue<T, BP>(q, wd_smem + fill * STAGE, wave, m_begin + (t + NSLOT - 1) * BP, m_end, disp, dv, xrow, xcol, ky, kx);
-        }
         const char* base = wd_smem + slot * STAGE;
+        // groups 0 .. NKS-2 of tile t, each under the fragment reads of the next group (NKS is even or odd: ping-pong by parity)
 #pragma unroll
-        for (int ks = 0; ks < BP / 16; ++ks) {
-            const T* xa = reinterpret_cast<const T*>(base + x_off + ks * 16 * WD_XP);
-            const auto blo = WgMma<T>::tr(xa), bup = WgMma<T>::tr(reinterpret_cast<const T*>(reinterpret_cast<const char*>(xa) + 8 * WD_XP));
-            const typename WgMma<T>::Frag bf = __builtin_shufflevector(blo, bup, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const char* da = base + d_off + ks * 16 * WD_DP + i * 64;
-                const auto alo = WgMma<T>::tr(reinterpret_cast<const T*>(da)), aup = WgMma<T>::tr(reinterpret_cast<const T*>(da + 8 * WD_DP));
-                const typename WgMma<T>::Frag a = __builtin_shufflevector(alo, aup, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[i] = WgMma<T>::mma(a, bf, acc[i]);
-            }
+        for (int ks = 0; ks + 1 < NKS; ++ks) {
+            if (ks & 1) { load_frags(fa, base, ks + 1); mma(fb); }
+            else { load_frags(fb, base, ks + 1); mma(fa); }
         }
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        Frags& last = ((NKS - 1) & 1) ? fb : fa;            // holds group NKS-1 of tile t
+        Frags& next = ((NKS - 1) & 1) ? fa : fb;
+        const int nslot = slot + 1 == NSLOT ? 0 : slot + 1;
+        if (t + 1 < n_tile) {
+            // tile t+1 must have landed (younger: t+2 .. t+NSLOT-1 if they exist); every wave's reads of tile t are done (lgkmcnt)
+            const int younger = min(n_tile - 2 - t, NSLOT - 2);
+            if (NSLOT == 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PW) : "memory");
+            else if (NSLOT >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + NSLOT < n_tile)        // tile t's slot is free now
+                wd_issue<T, BP>(q, wd_smem + slot * STAGE, wave, m_begin + (t + NSLOT) * BP, m_end, disp, dv, xrow, xcol, ky, kx);
+            load_frags(next, wd_smem + nslot * STAGE, 0);
+        }
+        mma(last);
+        if constexpr ((NKS & 1) != 0) {       // odd group count: tile t+1's group 0 sits in the other set -- swap roles by copying
+            if (t + 1 < n_tile) fa = next;
+        }
+        slot = nslot;
     }
 
     // partial tile -> slab [split][n][tap * ctot + c]
@@ -447,7 +480,7 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
     // one workgroup per CU: whole rounds of 256, at least 4 pixel steps per split
     static const int kBp = getenv("MVLDM_WGRAD_WIDE_BP") ? atoi(getenv("MVLDM_WGRAD_WIDE_BP")) : 64;      // 64: 2-slot ring (default), 32: 4-slot (measured 18 % slower)
     const int tiles = p.tiles_n * p.taps * p.tiles_c, blocks = cdiv_(p.M, 64);
-    static const int kTarget = getenv("MVLDM_WGRAD_WIDE_TARGET") ? atoi(getenv("MVLDM_WGRAD_WIDE_TARGET")) : 512;
+    static const int kTarget = getenv("MVLDM_WGRAD_WIDE_TARGET") ? atoi(getenv("MVLDM_WGRAD_WIDE_TARGET")) : 256;      // one round of workgroups: half the slab traffic of two (512: 2324 us over tools/wgrad_bench.py, 256: 2190)
     splits = std::max(1, std::min(kTarget / std::max(tiles, 1), std::max(1, blocks / 4)));
     const size_t slab = (size_t)d.n_out * p.kdim * sizeof(float);
     while (splits > 1 && (size_t)splits * slab > d.workspace_bytes) --splits;
@@ -458,7 +491,7 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
     p.n_splits = splits;
     p.xcd_map = kWgXcd;
     const dim3 grid(wg_grid(tiles, splits));
-    static std::atomic<uint64_t> done_b{0}, done_h{0}, done_b32{0}, done_h32{0};
+    static std::atomic<uint64_t> done_b{0}, done_h{0}, done_b32{0}, done_h32{0}, done_b48{0}, done_h48{0};
     rc = dispatch_dtype(d.act_dtype, [&](auto t) {
         using T = decltype(t);
         if constexpr (sizeof(T) == 2) {
@@ -467,6 +500,10 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
                 auto* kern = wgrad_dma_kernel<T, 64>;
                 if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), WD_RING, B16 ? done_b : done_h)) return rc0;
                 hipLaunchKernelGGL(kern, grid, dim3(512), WD_RING, s, q);
+            } else if (kBp == 48) {
+                auto* kern = wgrad_dma_kernel<T, 48>;
+                if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), 3 * 48 * 1024, B16 ? done_b48 : done_h48)) return rc0;
+                hipLaunchKernelGGL(kern, grid, dim3(512), 3 * 48 * 1024, s, q);
             } else {
                 auto* kern = wgrad_dma_kernel<T, 32>;
                 if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(kern), WD_RING, B16 ? done_b32 : done_h32)) return rc0;

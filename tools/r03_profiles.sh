@@ -17,7 +17,21 @@ python3 tools/pmc_traffic.py $F $W $R/gpurun_out/r03_pmc_traffic.json 192 bf16_b
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03 -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-small-batch --no-parity --no-train-line --no-alt-dtype > $R/gpurun_out/r03_prof_bench.log 2>&1
 S=$(find $R/gpurun_out/prof_r03 -name "bench_kernel_stats.csv" | head -1)
 cp $S $R/gpurun_out/r03_kernel_stats.csv
+# attention counters (d = 40 level-0 3-D block and d = 64 SD self-attention at 64 scenes), the weight-gradient forms
+bash $R/tools/pmc_kernels.sh r03_attn40 python3 tools/attn_one.py 40 8 64 > /dev/null 2>&1
+bash $R/tools/pmc_kernels.sh r03_attn64 python3 tools/attn_one.py 64 5 64 > /dev/null 2>&1
+python3 - <<'PY'
+import json, os
+R = os.environ["GRAFT_REPO_ROOT"]
+out = {}
+for tag, what in (("r03_attn40", "level-0 3-D attention: 8 heads x 40, 64 scenes (5120 + 4096 keys)"), ("r03_attn64", "SD self-attention shape: 5 heads x 64, 64 scenes")):
+    d = json.load(open(f"{R}/gpurun_out/pmc_{tag}.json"))
+    out[what] = {k: v for k, v in d.items() if "attention" in k}
+json.dump(out, open(f"{R}/gpurun_out/r03_attention_pmc.json", "w"), indent=1)
+PY
+python3 tools/attn_bench.py 64 > $R/gpurun_out/r03_attn_bench.txt 2>&1
 # the raw traces are large: keep the summaries only
+rm -rf $R/gpurun_out/pmc_r03_attn40 $R/gpurun_out/pmc_r03_attn64
 rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/prof_r03 $R/gpurun_out/pmc_r03_unet
 head -8 $R/gpurun_out/r03_kernel_stats.csv | cut -c1-200
 tail -c 400 $R/gpurun_out/r03_bench.json
