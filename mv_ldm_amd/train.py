@@ -1125,9 +1125,28 @@ class MVLDMTrainer:
         return tp
 
     def _fresh(self, tp: TrainPlan):
+        ev = tp.__dict__.pop("_repack_event", None)
+        if ev is not None:                           # re-packed ahead of time on the side stream (`_repack_ahead`)
+            torch.cuda.current_stream().wait_event(ev)
         if tp.weights_gen != self._weights_gen:      # only the plan about to run re-packs (cond / uncond / other shapes wait their turn)
             tp.refresh_weights()
             tp.weights_gen = self._weights_gen
+
+    def _repack_ahead(self, tp: TrainPlan):
+        """right after an optimizer step: re-pack the weights of the plan that just ran on a SIDE stream, so that the ~380 small
+        memory-bound packing launches (5 ms) run under the next window's VAE encode and input staging (compute-bound, independent of
+        the denoiser weights) instead of in front of its forward pass.  The next `_fresh(tp)` waits for the event; a different plan
+        shape next time re-packs lazily as before.  MVLDM_TRAIN_REPACK_AHEAD=0 disables it."""
+        if os.environ.get("MVLDM_TRAIN_REPACK_AHEAD", "1") == "0" or not torch.cuda.is_available():
+            return
+        side = self.__dict__.get("_side_stream")
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.flat.flat.device)
+        side.wait_stream(torch.cuda.current_stream())        # the updated (and, under ZeRO-1, gathered) parameters
+        with torch.cuda.stream(side):
+            tp.refresh_weights()
+            tp._repack_event = side.record_event()
+        tp.weights_gen = self._weights_gen
 
     def training_step(self, batch, **choices) -> torch.Tensor:
         """one micro-batch: forward + loss + backward (gradients accumulate in the flat buffer); every
@@ -1154,6 +1173,7 @@ class MVLDMTrainer:
             self.opt.step()
             self.global_step += 1
             self._weights_gen += 1
+            self._repack_ahead(tp)
         return loss.squeeze(0)
 
     def training_window(self, batches: Sequence[dict], choices: Optional[Sequence[dict]] = None) -> torch.Tensor:
@@ -1194,6 +1214,7 @@ class MVLDMTrainer:
         self.opt.step()
         self.global_step += 1
         self._weights_gen += 1
+        self._repack_ahead(tp)
         return losses
 
     def _run_overlapped(self, tp: TrainPlan):
