@@ -339,6 +339,13 @@ int mvldm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, flo
  * fp32 parameter buffer (the first update is a plain copy, done by the caller).  avg += weight (p - avg), torch's lerp arithmetic. */
 int mvldm_ema_update(float* avg, const float* p, size_t n, float weight, mvldm_stream_t stream);
 
+/* dst row k = src row index[k], k < n_rows; rows of row_bytes bytes (a multiple of 16), src and dst may be the same buffer as long as
+ * no destination row is also a source row.  Used by the fused CFG forward: the unconditional pass of DiffusionWrapper.step
+ * (diffusion_wrapper.py:437-441) feeds the target views the SAME latents, mask, rays and timestep as the conditional pass, and every
+ * layer before the first multi-view attention block works per image -- those layers run once on the conditional images and the target
+ * views' feature maps are copied into the unconditional rows (mv_ldm_amd/mvunet.py, `dup`). */
+int mvldm_gather_rows(const void* src, void* dst, const int32_t* index, int n_rows, size_t row_bytes, mvldm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Plans: a whole forward (UNet walk, VAE decoder, DDIM step) as a flat list of the ops above with
  * all pointers resolved -- built once by the host (mv_ldm_amd/plan.py), executed here without
@@ -356,7 +363,8 @@ enum {
      * others on the plan's own side streams, forked and joined with events -- under capture these become parallel branches of the
      * hipGraph (the four sub-pixel phase convs of an upsampler, a resnet's 1x1 shortcut beside its main chain: what fills the chip at
      * one or two scenes).  mvldm_op_run and mvldm_plan_profile treat them as no-ops (serial order is always valid). */
-    MVLDM_OP_PAR_BEGIN, MVLDM_OP_PAR_NEXT, MVLDM_OP_PAR_END
+    MVLDM_OP_PAR_BEGIN, MVLDM_OP_PAR_NEXT, MVLDM_OP_PAR_END,
+    MVLDM_OP_GATHER_ROWS
 };
 
 typedef struct mvldm_op {
@@ -401,6 +409,7 @@ typedef struct mvldm_op {
                  int32_t n_tgt, hw, c, accumulate, dpred_c, dpred_dtype; float loss_scale, grad_scale; } mse;
         struct { void* dst; size_t bytes; } fill;
         struct { const void* src; void* dst; size_t bytes; } memcpy_;
+        struct { const void* src; void* dst; const int32_t* index; size_t row_bytes; int32_t n_rows; } gather;
     } u;
 } mvldm_op;
 

@@ -211,7 +211,7 @@ class ResnetBlock2D(nn.Module):
         self.nonlinearity = nn.SiLU()
         self.conv_shortcut = Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
-    def emit(self, b: Builder, x, temb=None, x2=None, temb_proj=None):
+    def emit(self, b: Builder, x, temb=None, x2=None, temb_proj=None, out=None):
         """x (+ x2 = skip tensor, concatenated along C on the fly).  `temb_proj`: precomputed
         time_emb_proj(silu(emb)) rows [n_img, out_channels] fp32 (plan mode computes all resnets' at once)."""
         if self.time_emb_proj is not None and temb_proj is None:
@@ -240,7 +240,7 @@ class ResnetBlock2D(nn.Module):
         else:
             g2 = main_chain()
             sc = self.conv_shortcut.emit(b, x, x2=x2, name="conv_shortcut")
-        out = self.conv2.emit(b, g2, residual=sc, name="conv2")
+        out = self.conv2.emit(b, g2, residual=sc, name="conv2", **({} if out is None else {"out": out}))
         b.free(g2)
         if sc is not x:
             b.free(sc)
@@ -395,7 +395,8 @@ class Transformer2DModel(nn.Module):
             return mod.emit(b, x2d, **kw)
         return b.linear(x2d, mod.packed(b.dtype, x2d.shape[-1]), mod._f32("bias"), **kw)  # 1x1 conv == linear on tokens
 
-    def emit(self, b: Builder, x, ctx=None, zero_ctx=False):
+    def emit(self, b: Builder, x, ctx=None, zero_ctx=False, out=None):
+        """`out`: optional NHWC destination of the block's result (a view of a larger batch buffer)"""
         n, h, w, c = x.shape
         g = self.norm.emit(b, x, name="norm")
         hs = self._proj(b, self.proj_in, g.view(n * h * w, c), name="proj_in")
@@ -410,7 +411,7 @@ class Transformer2DModel(nn.Module):
                 nxt = blk.emit(b, hs, n, h * w, ctx2d, ctx_tokens, zero_ctx)
             b.free(hs)
             hs = nxt
-        out = self._proj(b, self.proj_out, hs, residual=x.view(n * h * w, c), name="proj_out")
+        out = self._proj(b, self.proj_out, hs, residual=x.view(n * h * w, c), name="proj_out", **({} if out is None else {"out": out.view(n * h * w, c)}))
         b.free(hs)
         return out.view(n, h, w, c)
 
@@ -433,8 +434,8 @@ class Downsample2D(nn.Module):
         self.padding = padding
         self.conv = Conv2d(channels, out_channels or channels, 3, stride=2, padding=padding)
 
-    def emit(self, b: Builder, x):
-        return self.conv.emit(b, x, name="downsample")   # padding 0 => asymmetric (0,1,0,1) zero pad in-kernel
+    def emit(self, b: Builder, x, out=None):
+        return self.conv.emit(b, x, name="downsample", **({} if out is None else {"out": out}))   # padding 0 => asymmetric (0,1,0,1) zero pad in-kernel
 
     def forward(self, x):
         b = eager_builder(x)

@@ -235,7 +235,9 @@ class MVLDMPipeline:
         groups = [v] * b + ([v_t] * b if use_cfg else [])
         bld = Builder(dev, dtype, record=True)
         with bld.scope("unet"):
-            den.emit(bld, unet_in, timesteps, groups, out=eps)
+            # the unconditional images [n_cond, n_img) re-submit the target views cond_img of the conditional pass: the layers in front
+            # of the first multi-view block run once for both (mvunet.MultiViewUNet.emit, `dup`)
+            den.emit(bld, unet_in, timesteps, groups, out=eps, dup=(n_cond, cond_img) if use_cfg else None)
         bld.ddim_step(eps, x_state, x_state, cond_img, unc_img, self.cfg.cfg_scale, coef, step_ptr, unet_in,
                       clip_range=sch.clip_range)
         bld.ddim_advance(step_ptr, t_table, timesteps, tgt_rows)

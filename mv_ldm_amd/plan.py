@@ -363,6 +363,18 @@ class Builder:
         op.u.memcpy_.src, op.u.memcpy_.dst, op.u.memcpy_.bytes = ptr(src), ptr(dst), src.numel() * src.element_size()
         self._emit(op, name, 0.0, 2.0 * src.numel() * src.element_size(), (dst, src))
 
+    def gather_rows(self, src, dst, index, name="gather_rows"):
+        """dst[k] = src[index[k]] over the leading dimension (rows = whole images); src and dst may alias (disjoint rows)"""
+        n = index.numel()
+        row_bytes = dst[0].numel() * dst.element_size()
+        assert dst.shape[0] == n and src[0].numel() * src.element_size() == row_bytes and row_bytes % 16 == 0
+        assert index.dtype == torch.int32 and dst.is_contiguous() and src.is_contiguous()
+        op = L.Op()
+        op.kind = L.OP_GATHER_ROWS
+        g = op.u.gather
+        g.src, g.dst, g.index, g.row_bytes, g.n_rows = ptr(src), ptr(dst), ptr(index), row_bytes, n
+        self._emit(op, name, 0.0, 2.0 * n * row_bytes, (src, dst, index))
+
     def nhwc_to_nchw(self, src, dst, c=None, c_off=0, scale=1.0, shift=0.0, clamp01=False, name="nhwc_to_nchw"):
         n, h, w, sc = src.shape
         op = L.Op()

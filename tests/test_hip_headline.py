@@ -166,6 +166,37 @@ def test_rule_based_tiles_match_the_tuned_plan(models, monkeypatch, dtype):
     assert torch.isfinite(outs["0"]).all() and e < (1e-5 if dtype == torch.float32 else 1e-2), e
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
+    """the unconditional pass of classifier-free guidance re-submits the target views of the conditional pass; the layers in front
+    of the first multi-view block work per image, so the fused plan evaluates them once (`MultiViewUNet.emit(dup=...)`) and copies
+    the feature maps: x_{t-1} must equal the plan that walks all images (`MVLDM_CFG_SHARE=0`) -- f32 to accumulation-order
+    round-off of a differently tiled GEMM, bf16 to one rounding per layer -- and the oracle (the step test above runs with it on)"""
+    M, m, _ = models
+    v_c, v_t, b = 1, 4, 2
+    ctx_lat, x_t, extr, intr = _inputs(v_c, v_t, b=b, seed=13)
+    outs, n_ops = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MVLDM_CFG_SHARE", mode)
+        monkeypatch.setenv("MVLDM_AUTOTUNE", "0")
+        pipe = _pipe(m)
+        with M.compute_dtype(dtype):
+            st = pipe._compile(b, v_c, v_t, 32, 32, dtype, 50)
+            pipe.load_inputs(st, ctx_lat, x_t, (extr[:, :v_c], intr[:, :v_c]), (extr[:, v_c:], intr[:, v_c:]))
+            st["plan"].replay()
+            st["plan"].replay()
+            outs[mode] = pipe._read_state(st, b, v_t).cpu()
+        names = [mm.name for mm in st["plan"].meta]
+        n_ops[mode] = sum("cfg_share" in n for n in names)
+        pipe._plans.clear()
+    assert n_ops["1"] == 3 and n_ops["0"] == 0            # conv_in + the two level-0 skips are gathered, nothing else is copied
+    e = rel_err(outs["1"], outs["0"])
+    print(f"shared CFG prefix vs full walk [{dtype}], two DDIM steps: rel-err {e:.3e}")
+    # (bf16: the prefix GEMMs see 10 instead of 18 images, the rules pick other tiles, sums round differently: two bf16 evaluations
+    #  of one forward differ by about as much as each differs from f32, ~2e-2 in eps = ~2.5e-3 in x per step; measured 5.2e-3)
+    assert torch.isfinite(outs["1"]).all() and e < (2e-6 if dtype == torch.float32 else 1.5e-2), e
+
+
 def test_plans_follow_weight_changes(models):
     """recorded plans hold pointers to PACKED copies of the weights: after `load_state_dict` (Lightning's
     load_from_checkpoint), an in-place copy or an optimizer step the next forward must use the new weights"""

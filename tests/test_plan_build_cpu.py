@@ -173,3 +173,37 @@ def test_temporaries_freed_inside_a_parallel_group_wait_for_the_join(cpu_record)
         assert c.data_ptr() != a.data_ptr()
     d = b.empty(4, 8)                      # after the join it is free again
     assert d.data_ptr() == a.data_ptr()
+
+
+def test_shared_cfg_prefix_structure(cpu_record):
+    """`MultiViewUNet.emit(dup=(n_src, src_rows))`: conv_in and the level-0 down block (2 resnets + 2 SD transformer blocks, all
+    per-image work) run on the conditional images only, three row gathers fill the unconditional images' skip tensors right
+    before the first multi-view block, everything after walks the full batch; executed FLOPs drop by the prefix's share"""
+    m = mvunet.MultiViewUNet(mvunet.MultiViewUNetCfg(pretrained_from="sd21"), 11, 4)
+
+    def build(dup):
+        b = plan.Builder("cpu", torch.bfloat16, record=True, splitk_ws_bytes=1 << 20)
+        x = torch.zeros(18, 32, 32, 16, dtype=torch.bfloat16)
+        idx = torch.tensor([1, 2, 3, 4, 6, 7, 8, 9], dtype=torch.int32)
+        eps = m.emit(b, x, torch.zeros(18, dtype=torch.int64), [5, 5, 4, 4], dup=(10, idx) if dup else None)
+        assert eps.shape == (18, 32, 32, 4)
+        return b
+
+    full, shared = build(False), build(True)
+    assert len(shared.meta) == len(full.meta) + 3
+    gathers = [(op, mm) for op, mm in zip(shared.ops, shared.meta) if op.kind == L.OP_GATHER_ROWS]
+    assert [mm.name for _, mm in gathers] == ["unet/cfg_share/skip0", "unet/cfg_share/skip1", "unet/cfg_share/skip2"] or \
+        [mm.name.split("/")[-1] for _, mm in gathers] == ["skip0", "skip1", "skip2"]
+    assert all(op.u.gather.n_rows == 8 and op.u.gather.row_bytes == 32 * 32 * 320 * 2 for op, _ in gathers)
+    first_mv = next(i for i, mm in enumerate(shared.meta) if "mv_encoder.0" in mm.name)
+    for i, (op, mm) in enumerate(zip(shared.ops, shared.meta)):
+        if op.kind != L.OP_IGEMM or "time" in mm.name:
+            continue
+        rows = op.u.igemm.n_img * op.u.igemm.h_out * op.u.igemm.w_out
+        if i < first_mv:
+            assert rows == 10 * 1024, (mm.name, rows)          # the shared prefix: conditional images only
+        elif "mv_encoder.0" in mm.name or "up3" in mm.name:
+            assert rows == 18 * 1024, (mm.name, rows)          # full batch from the first multi-view block on
+    f_full, f_shared = sum(mm.flops for mm in full.meta), sum(mm.flops for mm in shared.meta)
+    prefix = sum(mm.flops for mm in full.meta[:next(i for i, mm in enumerate(full.meta) if "mv_encoder.0" in mm.name)])
+    assert abs((f_full - f_shared) / (prefix * 8 / 18) - 1) < 1e-2          # (the time-embedding GEMMs in front are not shared)
