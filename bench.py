@@ -348,6 +348,7 @@ def main():
         st = pipe.prepare(batch)
         plan.profile(1)
         ms = plan.profile(5)
+        from mv_ldm_amd import _lib as L_
         from mv_ldm_amd._lib import OP_ATTENTION, OP_GROUPNORM, OP_IGEMM, OP_LAYERNORM
         agg = {}
         for m, t in zip(plan.meta, ms):
@@ -363,7 +364,9 @@ def main():
                            "launches": ig[3], "avg_launch_us": round(1e3 * ig[0] / max(ig[3], 1), 2),
                            "share_of_step_time": round(ig[0] / tot_ms, 3),
                            "flops_per_pass": ig[1], "step_ms_eager_sum": round(tot_ms, 3)}
-        names = {OP_IGEMM: "igemm", OP_ATTENTION: "attention", OP_GROUPNORM: "groupnorm", OP_LAYERNORM: "layernorm"}
+        names = {OP_IGEMM: "igemm", OP_ATTENTION: "attention", OP_GROUPNORM: "groupnorm", OP_LAYERNORM: "layernorm",
+                 L_.OP_GATHER_ROWS: "cfg_share_gather", L_.OP_DDIM_STEP: "ddim_cfg_step", L_.OP_DDIM_ADVANCE: "ddim_advance",
+                 L_.OP_TIMESTEP_EMBED: "timestep_embed"}
         out["kernel_breakdown_ms"] = {names.get(k, f"op{k}"): round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         # the other kernel families of the step, each against the roof that bounds it (same HIP-event timings)
         other = []
