@@ -339,12 +339,14 @@ int mvldm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, flo
  * fp32 parameter buffer (the first update is a plain copy, done by the caller).  avg += weight (p - avg), torch's lerp arithmetic. */
 int mvldm_ema_update(float* avg, const float* p, size_t n, float weight, mvldm_stream_t stream);
 
-/* dst row k = src row index[k], k < n_rows; rows of row_bytes bytes (a multiple of 16), src and dst may be the same buffer as long as
- * no destination row is also a source row.  Used by the fused CFG forward: the unconditional pass of DiffusionWrapper.step
- * (diffusion_wrapper.py:437-441) feeds the target views the SAME latents, mask, rays and timestep as the conditional pass, and every
- * layer before the first multi-view attention block works per image -- those layers run once on the conditional images and the target
- * views' feature maps are copied into the unconditional rows (mv_ldm_amd/mvunet.py, `dup`). */
-int mvldm_gather_rows(const void* src, void* dst, const int32_t* index, int n_rows, size_t row_bytes, mvldm_stream_t stream);
+/* dst row (dst_index ? dst_index[k] : k) = src row (src_index ? src_index[k] : k), k < n_rows; rows of row_bytes bytes (a multiple of
+ * 16); src and dst may be the same buffer as long as no destination row is also a source row.  Used by the fused CFG forward: the
+ * unconditional pass of DiffusionWrapper.step (diffusion_wrapper.py:437-441) feeds the target views the SAME latents, mask, rays and
+ * timestep as the conditional pass, the context views never change during sampling, and every layer before the first multi-view
+ * attention block works per image -- those layers run once per step on the target views (and once per sample on the context views)
+ * and the feature maps are copied to the rows that need them (mv_ldm_amd/mvunet.py, `dup`). */
+int mvldm_gather_rows(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int n_rows, size_t row_bytes,
+                      mvldm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plans: a whole forward (UNet walk, VAE decoder, DDIM step) as a flat list of the ops above with
@@ -409,7 +411,7 @@ typedef struct mvldm_op {
                  int32_t n_tgt, hw, c, accumulate, dpred_c, dpred_dtype; float loss_scale, grad_scale; } mse;
         struct { void* dst; size_t bytes; } fill;
         struct { const void* src; void* dst; size_t bytes; } memcpy_;
-        struct { const void* src; void* dst; const int32_t* index; size_t row_bytes; int32_t n_rows; } gather;
+        struct { const void* src; void* dst; const int32_t* src_index; const int32_t* dst_index; size_t row_bytes; int32_t n_rows; } gather;
     } u;
 } mvldm_op;
 

@@ -93,7 +93,7 @@ class _Memcpy(C.Structure):
 
 
 class _Gather(C.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("index", vp), ("row_bytes", sz), ("n_rows", i32)]
+    _fields_ = [("src", vp), ("dst", vp), ("src_index", vp), ("dst_index", vp), ("row_bytes", sz), ("n_rows", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -192,7 +192,7 @@ SIGNATURES = {
     "mvldm_eltwise_fwd": (C.c_int, [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp]),
     "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
     "mvldm_ddim_advance": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp]),
-    "mvldm_gather_rows": (C.c_int, [vp, vp, vp, C.c_int, sz, vp]),
+    "mvldm_gather_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, sz, vp]),
     "mvldm_ddpm_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, sz, f32, vp, f32, vp]),
     "mvldm_ema_update": (C.c_int, [vp, vp, sz, f32, vp]),
     "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, vp, vp]),

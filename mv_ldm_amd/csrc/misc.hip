@@ -90,13 +90,14 @@ __global__ __launch_bounds__(256) void ddpm_kernel(const float* __restrict__ eps
     }
 }
 
-// dst row k = src row index[k] (16-byte chunks; one row = one image's NHWC feature map)
-__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, const int32_t* __restrict__ index,
-                                                          int n_rows, size_t chunks_per_row) {
+// dst row d(k) = src row s(k) with optional index vectors (16-byte chunks; one row = one image's NHWC feature map)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, const int32_t* __restrict__ src_index,
+                                                          const int32_t* __restrict__ dst_index, int n_rows, size_t chunks_per_row) {
     const size_t total = (size_t)n_rows * chunks_per_row;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / chunks_per_row, c = i - row * chunks_per_row;
-        dst[row * chunks_per_row + c] = src[(size_t)index[row] * chunks_per_row + c];
+        const size_t sr = src_index ? (size_t)src_index[row] : row, dr = dst_index ? (size_t)dst_index[row] : row;
+        dst[dr * chunks_per_row + c] = src[sr * chunks_per_row + c];
     }
 }
 
@@ -317,12 +318,12 @@ int ddpm_run(const float* eps_c, const float* eps_u, const float* x_t, const flo
     return check_launch();
 }
 
-int gather_rows_run(const void* src, void* dst, const int32_t* index, int n_rows, size_t row_bytes, hipStream_t s) {
+int gather_rows_run(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int n_rows, size_t row_bytes, hipStream_t s) {
     if (n_rows == 0 || row_bytes == 0) return MVLDM_OK;
-    MVLDM_REQUIRE(src && dst && index && row_bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "gather_rows: bad arguments");
+    MVLDM_REQUIRE(src && dst && row_bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "gather_rows: bad arguments");
     const size_t cpr = row_bytes / 16;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n_rows * cpr)), dim3(256), 0, s, reinterpret_cast<const u32x4*>(src),
-                       reinterpret_cast<u32x4*>(dst), index, n_rows, cpr);
+                       reinterpret_cast<u32x4*>(dst), src_index, dst_index, n_rows, cpr);
     return check_launch();
 }
 
@@ -372,8 +373,9 @@ extern "C" int mvldm_ddpm_cfg_step(const float* eps_c, const float* eps_u, const
                                    float cfg_scale, const float* coef, float clip_range, mvldm_stream_t stream) {
     return ddpm_run(eps_c, eps_u, x_t, noise, x_next, n, cfg_scale, coef, clip_range, (hipStream_t)stream);
 }
-extern "C" int mvldm_gather_rows(const void* src, void* dst, const int32_t* index, int n_rows, size_t row_bytes, mvldm_stream_t stream) {
-    return gather_rows_run(src, dst, index, n_rows, row_bytes, (hipStream_t)stream);
+extern "C" int mvldm_gather_rows(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int n_rows, size_t row_bytes,
+                                 mvldm_stream_t stream) {
+    return gather_rows_run(src, dst, src_index, dst_index, n_rows, row_bytes, (hipStream_t)stream);
 }
 extern "C" int mvldm_ddim_cfg_step(const float* eps, const float* x_t, float* x_next, const int32_t* cond_img,
                                    const int32_t* uncond_img, int n_tgt, int hw, int c, float cfg_scale, const float* coef,

@@ -43,7 +43,7 @@ int mse_run(const float* pred, const float* noise, const int32_t* tgt_img, int n
             void* dpred, int dc, int dtype, float grad_scale, double* ws, hipStream_t s);
 int to_nchw_run(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off, int src_dtype, float scale,
                 float shift, int clamp01, hipStream_t s);
-int gather_rows_run(const void* src, void* dst, const int32_t* index, int n_rows, size_t row_bytes, hipStream_t s);
+int gather_rows_run(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int n_rows, size_t row_bytes, hipStream_t s);
 
 static int run_op(const mvldm_op& op, hipStream_t s) {
     switch (op.kind) {
@@ -149,7 +149,7 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         }
         case MVLDM_OP_GATHER_ROWS: {
             const auto& g = op.u.gather;
-            return gather_rows_run(g.src, g.dst, g.index, g.n_rows, g.row_bytes, s);
+            return gather_rows_run(g.src, g.dst, g.src_index, g.dst_index, g.n_rows, g.row_bytes, s);
         }
         case MVLDM_OP_PAR_BEGIN:
         case MVLDM_OP_PAR_NEXT:

@@ -282,6 +282,14 @@ class Denoiser(nn.Module):
         self.cfg = cfg
 
 
+class _PrefixDone(Exception):
+    """`MultiViewUNet.emit(prefix_only=True)` reached the first multi-view block"""
+
+    def __init__(self, skips):
+        super().__init__()
+        self.skips = skips
+
+
 class MultiViewUNet(Denoiser, _PackMixin):
     def __init__(self, cfg: MultiViewUNetCfg, in_channels: int, out_channels: int):
         super().__init__(cfg)
@@ -336,25 +344,37 @@ class MultiViewUNet(Denoiser, _PackMixin):
         return cond_state is None
 
     def emit(self, b: Builder, x_in, timesteps, groups: Sequence[int], out: Optional[torch.Tensor] = None,
-             dup: Optional[Tuple[int, torch.Tensor]] = None):
+             dup: Optional[tuple] = None, prefix_only: bool = False):
         """x_in: NHWC [n_img, h, w, c_pad] (11 real channels, zero padded); timesteps: int64 [n_img];
         groups: views per scene for the 3-D attention.  Returns eps, fp32 NHWC [n_img, h, w, out_channels].
 
         `dup = (n_src, src_rows)`: images [n_src, n_img) carry exactly the inputs (latents, mask, rays, timestep) of images
         `src_rows[k]` (device int32 [n_img - n_src]) -- the unconditional pass of classifier-free guidance re-submits the target
         views of the conditional pass (diffusion_wrapper.py:437-441).  Every layer in front of the first multi-view attention block
-        works per image (convs, GroupNorm per image, per-view self-attention, time-embedding rows), so it is evaluated on the first
-        n_src images only and the duplicates' feature maps -- the running activation and the skip connections collected so far
-        -- are filled in by one row gather each right before that block.  Same arithmetic on the same values: the result is what
-        the full-batch walk gives (to the rounding of a different tile choice), at 256 / 576 of the level-0 down block's cost
-        for 1 context + 4 target views (5.6 % of a DDIM step at 64 scenes)."""
+        works per image (convs, GroupNorm per image, per-view self-attention, time-embedding rows), so it is evaluated once per
+        distinct input and the feature maps -- the running activation and the skip connections collected so far -- are copied
+        to the rows that share it by row gathers right before that block.  Same arithmetic on the same values: the result is what
+        the full-batch walk gives (to the rounding of a different tile choice).  Two forms:
+          * `(n_src, src_rows)`: the shared layers run on images [0, n_src) (conditional pass: context + target views), the
+            duplicates [n_src, n_img) are filled in: 320 instead of 576 images at 1 context + 4 target views;
+          * `(n_src, src_rows, const_rows, const_skips)`: additionally the images `const_rows` (the context views: their latents,
+            mask, rays and timestep 0 do not change during sampling) take their feature maps from `const_skips`, the tensors an
+            `emit(..., prefix_only=True)` over those images returned (the sampler's loader plan runs it once per sample); the
+            shared layers then run on the contiguous duplicate block [n_src, n_img) = one copy of every target view (256 images)
+            and both the rows `src_rows` and `const_rows` are filled in.
+        `prefix_only=True`: walk the shared layers only and return the list of feature maps collected up to the first multi-view
+        block (conv_in output, the down blocks' skip tensors) instead of eps."""
         u = self.unet
         n_img = x_in.shape[0]
         assert n_img == sum(groups)
         if dup is not None and (os.environ.get("MVLDM_CFG_SHARE", "1") == "0" or dup[0] >= n_img):
             dup = None
+        const = None
+        if dup is not None and len(dup) == 4:
+            const = (dup[2], dup[3]) if os.environ.get("MVLDM_CFG_SHARE", "1") != "1a" else None
         n_src = n_img if dup is None else int(dup[0])
-        shared = dup is not None          # True while only the first n_src images are being computed
+        shared = dup is not None          # True while only the distinct images are being computed
+        lo, hi = (n_src, n_img) if const is not None else (0, n_src)      # rows of the batch the shared layers run on
         with b.scope("time"):
             t_emb = u.time_proj.emit(b, timesteps, dtype=b.dtype)
             emb_act = u.time_embedding.emit(b, t_emb, silu_out=True)   # every consumer applies SiLU first
@@ -362,19 +382,16 @@ class MultiViewUNet(Denoiser, _PackMixin):
             tproj = self._temb_proj_all(b, emb_act)
             b.free(emb_act)
 
-        def full_like(t):          # the full-batch buffer a shared-prefix result is written into (its first n_src images)
-            return b.empty(n_img, *t.shape[1:], dtype=t.dtype)
-
         def dest(shape_of):        # `out=` for the op that produces a skip / the running activation while the prefix is shared
             if not shared:
                 return {}, None
             full = b.empty(n_img, *shape_of, dtype=b.dtype)
-            return {"out": full[:n_src]}, full
+            return {"out": full[lo:hi]}, full
 
         def resnet(r, name, h, skip=None, **kw):
             with b.scope(name):
                 tp_ = tproj[id(r)]
-                return r.emit(b, h, None, x2=skip, temb_proj=tp_[:h.shape[0]] if shared else tp_, **kw)
+                return r.emit(b, h, None, x2=skip, temb_proj=tp_[lo:hi] if shared else tp_, **kw)
 
         def sd_attn(attn, name, h, **kw):
             with b.scope(name):
@@ -382,26 +399,29 @@ class MultiViewUNet(Denoiser, _PackMixin):
 
         fulls = {}                 # id(prefix view) -> its full-batch buffer
 
+        def fill(full, i, name):
+            """rows of a full-batch feature map that did not compute it themselves"""
+            if const is None:
+                b.gather_rows(full, full[n_src:], src_index=dup[1], name=name)                     # duplicates <- their sources
+            else:
+                b.gather_rows(full[n_src:], full, dst_index=dup[1], name=name)                     # sources <- the duplicate block
+                b.gather_rows(const[1][i], full, dst_index=const[0], name=name + ".const")         # constant rows <- the per-sample store
+
         def expand(h):
-            """the prefix ends here: fill the duplicate images of the running activation and of every skip collected so far"""
+            """the prefix ends here: fill the other images of the running activation and of every skip collected so far"""
             nonlocal shared
+            if prefix_only:
+                raise _PrefixDone(list(skips))
             if not shared:
                 return h
             shared = False
             with b.scope("cfg_share"):
                 for i, t in enumerate(skips):
                     full = fulls[id(t)]
-                    b.gather_rows(full, full[n_src:], dup[1], name=f"skip{i}")
+                    fill(full, i, f"skip{i}")
                     skips[i] = full
-                if id(h) in fulls:
-                    hf = fulls[id(h)]
-                    if not any(hf is t for t in skips):
-                        b.gather_rows(hf, hf[n_src:], dup[1], name="h")
-                    return hf
-                hf = full_like(h)          # a prefix result that was not produced into a full buffer: copy + gather
-                b.memcpy(hf[:n_src], h, name="h.copy")
-                b.gather_rows(hf, hf[n_src:], dup[1], name="h")
-                return hf
+                assert id(h) in fulls and any(fulls[id(h)] is t for t in skips), "the running activation at a multi-view block is a skip"
+                return fulls[id(h)]
 
         def mv(blocks, idx, name, h):
             h = expand(h)
@@ -410,10 +430,16 @@ class MultiViewUNet(Denoiser, _PackMixin):
 
         with b.scope("conv_in"):
             kw, full = dest((x_in.shape[1], x_in.shape[2], u.conv_in.out_channels))
-            h = u.conv_in.emit(b, x_in[:n_src] if shared else x_in, name="conv", **kw)
+            h = u.conv_in.emit(b, x_in[lo:hi] if shared else x_in, name="conv", **kw)
             if full is not None:
                 fulls[id(h)] = full
         skips = [h]
+        try:
+            return self._emit_body(b, u, h, skips, fulls, dest, resnet, sd_attn, mv, expand, out, groups)
+        except _PrefixDone as done:
+            return done.skips
+
+    def _emit_body(self, b, u, h, skips, fulls, dest, resnet, sd_attn, mv, expand, out, groups):
         live_mv = None  # an MV-block output that is not a skip (freed once consumed)
         for lvl, blk in enumerate(u.down_blocks):
             has_attn = getattr(blk, "has_cross_attention", False)

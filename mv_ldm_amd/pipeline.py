@@ -17,6 +17,8 @@ into a hipGraph and replayed N times with no Python or host synchronisation in t
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional
 
@@ -233,11 +235,27 @@ class MVLDMPipeline:
         coef = sch.coefficient_table().to(dev)
         step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         groups = [v] * b + ([v_t] * b if use_cfg else [])
+        ctx_rows = torch.tensor([s * v + j for s in range(b) for j in range(v_c)], dtype=torch.int32, device=dev)
+        # Shared layers of the fused CFG forward (mvunet.MultiViewUNet.emit, `dup`): the unconditional images [n_cond, n_img) re-submit
+        # the target views cond_img of the conditional pass, and the context views' inputs (latents, mask 0, rays, timestep 0) do not
+        # change during sampling -- the layers in front of the first multi-view block run once per STEP on one copy of every target
+        # view and once per SAMPLE on the context views (`const_plan`, run by load_inputs after the loader plan).
+        dup, const_plan = None, None
+        if use_cfg and os.environ.get("MVLDM_CFG_SHARE", "1") != "0":
+            dup = (n_cond, cond_img)
+            if os.environ.get("MVLDM_CFG_SHARE", "1") != "1a":
+                cb = Builder(dev, dtype, record=True)
+                x_ctx = torch.zeros(b * v_c, hl, wl, c_pad, dtype=dtype, device=dev)
+                t_ctx = torch.zeros(b * v_c, dtype=torch.int64, device=dev)          # diffusion_wrapper.py:419: context timestep 0
+                cb.gather_rows(unet_in, x_ctx, src_index=ctx_rows, name="context rows")
+                with cb.scope("unet_ctx"):
+                    const_skips = den.emit(cb, x_ctx, t_ctx, [1] * (b * v_c), prefix_only=True)
+                cb.keep.extend([x_ctx, t_ctx, *const_skips])
+                const_plan = cb.finalize()
+                dup = (n_cond, cond_img, ctx_rows, const_skips)
         bld = Builder(dev, dtype, record=True)
         with bld.scope("unet"):
-            # the unconditional images [n_cond, n_img) re-submit the target views cond_img of the conditional pass: the layers in front
-            # of the first multi-view block run once for both (mvunet.MultiViewUNet.emit, `dup`)
-            den.emit(bld, unet_in, timesteps, groups, out=eps, dup=(n_cond, cond_img) if use_cfg else None)
+            den.emit(bld, unet_in, timesteps, groups, out=eps, dup=dup)
         bld.ddim_step(eps, x_state, x_state, cond_img, unc_img, self.cfg.cfg_scale, coef, step_ptr, unet_in,
                       clip_range=sch.clip_range)
         bld.ddim_advance(step_ptr, t_table, timesteps, tgt_rows)
@@ -251,7 +269,6 @@ class MVLDMPipeline:
         ones = torch.ones(b * v_t, 1, hl, wl, dtype=torch.float32, device=dev)
         extr = torch.zeros(n_img, 4, 4, dtype=torch.float32, device=dev)
         intr = torch.zeros(n_img, 3, 3, dtype=torch.float32, device=dev)
-        ctx_rows = torch.tensor([s * v + j for s in range(b) for j in range(v_c)], dtype=torch.int32, device=dev)
         minus_one = torch.full((1,), -1, dtype=torch.int32, device=dev)
         ld = Builder(dev, dtype, record=True)
         ld.memcpy(step_ptr, minus_one, name="step_ptr=-1")
@@ -263,7 +280,7 @@ class MVLDMPipeline:
         ld.ray_encode(extr, intr, hl, wl, unet_in, lc + 1, name="ray grid", **self.rays.kernel_args())
         ld.nchw_to_nhwc(x_T, x_state, 0, name="x_T -> fp32 state")
         loader = ld.finalize(autotune=False)
-        st = dict(plan=plan, loader=loader, unet_in=unet_in, x_state=x_state, eps=eps, timesteps=timesteps, cond_img=cond_img,
+        st = dict(plan=plan, loader=loader, const_plan=const_plan, unet_in=unet_in, x_state=x_state, eps=eps, timesteps=timesteps, cond_img=cond_img,
                   unc_img=unc_img, tgt_rows=tgt_rows, t_table=t_table, step_ptr=step_ptr, n_cond=n_cond,
                   ctx_lat=ctx_lat, x_T=x_T, extr=extr, intr=intr, weights_version=den.weights_version())
         self._plans[key] = st
@@ -283,6 +300,8 @@ class MVLDMPipeline:
             if st["unc_img"] is not None:
                 buf[n_cond:].copy_(ti.reshape(b * v_t, k, k))
         st["loader"].run()
+        if st.get("const_plan") is not None:      # the context views' shared layers: once per sample
+            st["const_plan"].run()
 
     def _scaled_noise(self, x_T):
         sigma = self.scheduler.init_noise_sigma        # 1.0 for DDIM (diffusion_wrapper.py:474)

@@ -363,17 +363,20 @@ class Builder:
         op.u.memcpy_.src, op.u.memcpy_.dst, op.u.memcpy_.bytes = ptr(src), ptr(dst), src.numel() * src.element_size()
         self._emit(op, name, 0.0, 2.0 * src.numel() * src.element_size(), (dst, src))
 
-    def gather_rows(self, src, dst, index, name="gather_rows"):
-        """dst[k] = src[index[k]] over the leading dimension (rows = whole images); src and dst may alias (disjoint rows)"""
-        n = index.numel()
+    def gather_rows(self, src, dst, src_index=None, dst_index=None, n_rows=None, name="gather_rows"):
+        """dst[dst_index[k] or k] = src[src_index[k] or k] over the leading dimension (rows = whole images), k < n_rows; src and dst
+        may alias (disjoint rows)"""
+        idx = src_index if src_index is not None else dst_index
+        n = int(n_rows if n_rows is not None else (idx.numel() if idx is not None else dst.shape[0]))
         row_bytes = dst[0].numel() * dst.element_size()
-        assert dst.shape[0] == n and src[0].numel() * src.element_size() == row_bytes and row_bytes % 16 == 0
-        assert index.dtype == torch.int32 and dst.is_contiguous() and src.is_contiguous()
+        assert src[0].numel() * src.element_size() == row_bytes and row_bytes % 16 == 0 and dst.is_contiguous() and src.is_contiguous()
+        assert all(i is None or (i.dtype == torch.int32 and i.numel() == n) for i in (src_index, dst_index))
+        assert (src_index is not None or src.shape[0] >= n) and (dst_index is not None or dst.shape[0] >= n)
         op = L.Op()
         op.kind = L.OP_GATHER_ROWS
         g = op.u.gather
-        g.src, g.dst, g.index, g.row_bytes, g.n_rows = ptr(src), ptr(dst), ptr(index), row_bytes, n
-        self._emit(op, name, 0.0, 2.0 * n * row_bytes, (src, dst, index))
+        g.src, g.dst, g.src_index, g.dst_index, g.row_bytes, g.n_rows = ptr(src), ptr(dst), ptr(src_index), ptr(dst_index), row_bytes, n
+        self._emit(op, name, 0.0, 2.0 * n * row_bytes, (src, dst, src_index, dst_index))
 
     def nhwc_to_nchw(self, src, dst, c=None, c_off=0, scale=1.0, shift=0.0, clamp01=False, name="nhwc_to_nchw"):
         n, h, w, sc = src.shape

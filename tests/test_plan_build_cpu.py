@@ -204,6 +204,21 @@ def test_shared_cfg_prefix_structure(cpu_record):
             assert rows == 10 * 1024, (mm.name, rows)          # the shared prefix: conditional images only
         elif "mv_encoder.0" in mm.name or "up3" in mm.name:
             assert rows == 18 * 1024, (mm.name, rows)          # full batch from the first multi-view block on
+    # second form: the context views (rows 0 and 5) come from a per-sample store, the shared layers run on the duplicate block
+    cb = plan.Builder("cpu", torch.bfloat16, record=True, splitk_ws_bytes=1 << 20)
+    store = m.emit(cb, torch.zeros(2, 32, 32, 16, dtype=torch.bfloat16), torch.zeros(2, dtype=torch.int64), [1, 1], prefix_only=True)
+    assert [tuple(t.shape) for t in store] == [(2, 32, 32, 320)] * 3
+    assert not any("mv_" in mm.name for mm in cb.meta) and sum(mm.kind == L.OP_IGEMM for mm in cb.meta) == 3 + 1 + 4 + 2 * 6
+    b2 = plan.Builder("cpu", torch.bfloat16, record=True, splitk_ws_bytes=1 << 20)
+    idx = torch.tensor([1, 2, 3, 4, 6, 7, 8, 9], dtype=torch.int32)
+    ctx = torch.tensor([0, 5], dtype=torch.int32)
+    m.emit(b2, torch.zeros(18, 32, 32, 16, dtype=torch.bfloat16), torch.zeros(18, dtype=torch.int64), [5, 5, 4, 4], dup=(10, idx, ctx, store))
+    g2 = [(op, mm) for op, mm in zip(b2.ops, b2.meta) if op.kind == L.OP_GATHER_ROWS]
+    assert len(g2) == 6 and [op.u.gather.n_rows for op, _ in g2] == [8, 2] * 3
+    first_mv2 = next(i for i, mm in enumerate(b2.meta) if "mv_encoder.0" in mm.name)
+    for i, (op, mm) in enumerate(zip(b2.ops, b2.meta)):
+        if op.kind == L.OP_IGEMM and "time" not in mm.name and i < first_mv2:
+            assert op.u.igemm.n_img * op.u.igemm.h_out * op.u.igemm.w_out == 8 * 1024, mm.name      # one copy of every target view
     f_full, f_shared = sum(mm.flops for mm in full.meta), sum(mm.flops for mm in shared.meta)
     prefix = sum(mm.flops for mm in full.meta[:next(i for i, mm in enumerate(full.meta) if "mv_encoder.0" in mm.name)])
     assert abs((f_full - f_shared) / (prefix * 8 / 18) - 1) < 1e-2          # (the time-embedding GEMMs in front are not shared)
