@@ -31,7 +31,7 @@ def test_hot_kernels_use_no_scratch(resources):
     registers, are no longer instantiated -- the library refuses that combination).  Forward attention is compiled to an
     occupancy target (4 / 3 / 2 waves per SIMD by head dim); since the K / V staging went to buffer descriptors (round 3) the
     kernels of the UNet's head dims (DP <= 64: d = 40, 64) are spill-free up to one register outside the loop."""
-    hot = re.compile(r"igemm_bl_kernelIDF16[b_]|igemm_halo_kernelIDF16[b_]|linear_pp_kernel")
+    hot = re.compile(r"igemm_bl_kernelIDF16[b_]|igemm_halo_kernelIDF16[b_]|linear_pp_kernel|wgrad_dma_kernel|wgrad_kernelIDF16")
     bad = {k: (v["scratch"], v.get("vgpr_spill", 0)) for k, v in resources.items()
            if hot.search(k) and (v["scratch"] or v.get("vgpr_spill", 0))}
     assert not bad, bad
