@@ -24,7 +24,10 @@
 extern "C" {
 #endif
 
-#define MVLDM_ABI_VERSION 2
+/* 3 (round 3): + mvldm_gather_rows, mvldm_ddpm_cfg_step, mvldm_ema_update; plan ops MVLDM_OP_PAR_BEGIN / _NEXT / _END and
+ * MVLDM_OP_GATHER_ROWS; bits 8-9 of mvldm_wgrad_desc.accumulate select the weight-gradient kernel form.  Everything of version 2 is
+ * unchanged (additive). */
+#define MVLDM_ABI_VERSION 3
 
 typedef void* mvldm_stream_t; /* hipStream_t */
 

@@ -11,7 +11,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmvldm_hip.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_GEGLU, EPI_GELU = 0, 1, 2, 3
 RAYS_RAW, RAYS_POSITIONAL, RAYS_SRT = 0, 1, 2

@@ -285,12 +285,14 @@ class Attention(nn.Module, _PackMixin):
             return self.to_out[0]._f32("bias")
         return self._cache(("bsum",), [bo, extra], lambda: (bo.detach().float() + extra.detach().float()).contiguous())
 
-    def emit_self(self, b: Builder, xn, residual, seg, lens, extra_bias=None, name="attn"):
-        """xn: normalised tokens [M, C]; one fused QKV projection, flash attention, out-proj + residual"""
+    def emit_self(self, b: Builder, xn, residual, seg, lens, extra_bias=None, name="attn", kv_lens=None):
+        """xn: normalised tokens [M, C]; one fused QKV projection, flash attention, out-proj + residual.  `kv_lens` (with a `seg`
+        whose query ranges are sub-ranges of the key ranges): only those query rows are attended and written."""
         C = self.inner
         qkv = b.linear(xn, self._packed_cat(b.dtype, [self.to_q, self.to_k, self.to_v]),
                        self._bias_cat([self.to_q, self.to_k, self.to_v]), name=name + ".to_qkv")
-        a = b.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.heads, self.dim_head, seg, lens, lens, name=name + ".sdpa")
+        a = b.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.heads, self.dim_head, seg, lens, lens if kv_lens is None else kv_lens,
+                        name=name + ".sdpa")
         b.free(qkv)
         out = b.linear(a, self.to_out[0].packed(b.dtype), self.out_bias(extra_bias), residual=residual, name=name + ".to_out")
         b.free(a)

@@ -111,11 +111,31 @@ class BasicTransformerBlock3D(nn.Module):
         self.norm2 = LayerNorm(dim)
         self.norm3 = LayerNorm(dim)
 
-    def emit(self, b: Builder, hs, groups: Sequence[int], tokens: int):
+    def emit(self, b: Builder, hs, groups: Sequence[int], tokens: int, keep=None):
+        """`keep = (keep_rows, drops)`: only the views `keep_rows` (device int32 image rows; per group the first `drops[g]` views are
+        dropped) are needed downstream -- the last multi-view block of the sampler, whose context-view outputs nothing reads: the
+        3-D attention skips the dropped views' queries (their keys / values still serve the others) and everything behind it runs
+        on the kept views, compacted.  Returns the compact token matrix [len(keep_rows) * tokens, C] then."""
         scene_lens = [g * tokens for g in groups]
-        view_lens = [tokens] * sum(groups)
         n1 = self.norm1.emit(b, hs, name="norm1")
-        h1 = self.attn1.emit_self(b, n1, hs, _segments(b, scene_lens), scene_lens, name="attn1_3d")
+        if keep is None:
+            n_views = sum(groups)
+            h1 = self.attn1.emit_self(b, n1, hs, _segments(b, scene_lens), scene_lens, name="attn1_3d")
+        else:
+            keep_rows, drops = keep
+            n_views = keep_rows.numel()
+            seg, row0 = [], 0
+            for g, d in zip(groups, drops):
+                seg.append([row0 + d * tokens, (g - d) * tokens, row0, g * tokens])
+                row0 += g * tokens
+            seg_t = torch.tensor(seg, dtype=torch.int32, device=b.device)
+            b.keep.append(seg_t)
+            full = self.attn1.emit_self(b, n1, hs, seg_t, [(g - d) * tokens for g, d in zip(groups, drops)], name="attn1_3d", kv_lens=scene_lens)
+            c = full.shape[-1]
+            h1 = b.empty(n_views * tokens, c, dtype=full.dtype)
+            b.gather_rows(full.view(sum(groups), tokens * c), h1.view(n_views, tokens * c), src_index=keep_rows, name="keep_views")
+            b.free(full)
+        view_lens = [tokens] * n_views
         b.free(n1)
         n2 = self.norm2.emit(b, h1, name="norm2")
         h2 = self.attn2.emit_self(b, n2, h1, _segments(b, view_lens), view_lens, name="attn2_view")
@@ -144,21 +164,30 @@ class SpatialTransformer3D(nn.Module):
         nn.init.zeros_(self.proj_out.weight)
         nn.init.zeros_(self.proj_out.bias)
 
-    def emit(self, b: Builder, x, groups: Sequence[int]):
-        """x: NHWC [sum(groups), h, w, C]; `groups` = number of views of each scene."""
+    def emit(self, b: Builder, x, groups: Sequence[int], keep=None):
+        """x: NHWC [sum(groups), h, w, C]; `groups` = number of views of each scene.  `keep`: see BasicTransformerBlock3D.emit --
+        the result then holds the kept views only, [len(keep_rows), h, w, C]."""
         n, h, w, c = x.shape
         assert n == sum(groups)
         g = self.norm.emit(b, x, name="norm")
         hs = b.linear(g.view(n * h * w, c), self.proj_in.packed(b.dtype, c), self.proj_in._f32("bias"), name="proj_in")
         b.free(g)
+        last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             with b.scope(f"transformer_blocks.{i}"):
-                nxt = blk.emit(b, hs, groups, h * w)
+                nxt = blk.emit(b, hs, groups, h * w, keep=keep if i == last else None)
             b.free(hs)
             hs = nxt
-        out = b.linear(hs, self.proj_out.packed(b.dtype, c), self.proj_out._f32("bias"), residual=x.view(n * h * w, c), name="proj_out")
+        res, n_out = x, n
+        if keep is not None:
+            n_out = keep[0].numel()
+            res = b.empty(n_out, h, w, c, dtype=x.dtype)
+            b.gather_rows(x, res, src_index=keep[0], name="keep_views.residual")
+        out = b.linear(hs, self.proj_out.packed(b.dtype, c), self.proj_out._f32("bias"), residual=res.view(n_out * h * w, c), name="proj_out")
         b.free(hs)
-        return out.view(n, h, w, c)
+        if keep is not None:
+            b.free(res)
+        return out.view(n_out, h, w, c)
 
     def forward(self, x, context=None):
         bsz, v, c, h, w = x.shape
@@ -344,7 +373,7 @@ class MultiViewUNet(Denoiser, _PackMixin):
         return cond_state is None
 
     def emit(self, b: Builder, x_in, timesteps, groups: Sequence[int], out: Optional[torch.Tensor] = None,
-             dup: Optional[tuple] = None, prefix_only: bool = False):
+             dup: Optional[tuple] = None, prefix_only: bool = False, tail: Optional[tuple] = None):
         """x_in: NHWC [n_img, h, w, c_pad] (11 real channels, zero padded); timesteps: int64 [n_img];
         groups: views per scene for the 3-D attention.  Returns eps, fp32 NHWC [n_img, h, w, out_channels].
 
@@ -363,7 +392,13 @@ class MultiViewUNet(Denoiser, _PackMixin):
             shared layers then run on the contiguous duplicate block [n_src, n_img) = one copy of every target view (256 images)
             and both the rows `src_rows` and `const_rows` are filled in.
         `prefix_only=True`: walk the shared layers only and return the list of feature maps collected up to the first multi-view
-        block (conv_in output, the down blocks' skip tensors) instead of eps."""
+        block (conv_in output, the down blocks' skip tensors) instead of eps.
+
+        `tail = (keep_rows, drops)`: only the eps of the images `keep_rows` is read (the sampler: the target views; the context
+        views' prediction is never used, diffusion_wrapper.py:444-451).  When the last multi-view block sits in the last up block,
+        nothing behind its 3-D attention mixes images any more: that attention skips the other views' queries, the rest of the
+        block and the output stage run on the kept views only, and their eps is scattered back to the full layout (the other
+        rows of eps are left undefined).  `drops[g]` = number of leading views of group g that are not kept."""
         u = self.unet
         n_img = x_in.shape[0]
         assert n_img == sum(groups)
@@ -423,10 +458,10 @@ class MultiViewUNet(Denoiser, _PackMixin):
                 assert id(h) in fulls and any(fulls[id(h)] is t for t in skips), "the running activation at a multi-view block is a skip"
                 return fulls[id(h)]
 
-        def mv(blocks, idx, name, h):
+        def mv(blocks, idx, name, h, **kw):
             h = expand(h)
             with b.scope(name):
-                return blocks[idx].emit(b, h, groups)
+                return blocks[idx].emit(b, h, groups, **kw)
 
         with b.scope("conv_in"):
             kw, full = dest((x_in.shape[1], x_in.shape[2], u.conv_in.out_channels))
@@ -435,12 +470,16 @@ class MultiViewUNet(Denoiser, _PackMixin):
                 fulls[id(h)] = full
         skips = [h]
         try:
-            return self._emit_body(b, u, h, skips, fulls, dest, resnet, sd_attn, mv, expand, out, groups)
+            if tail is not None and os.environ.get("MVLDM_TAIL_DROP", "1") == "0":
+                tail = None
+            return self._emit_body(b, u, h, skips, fulls, dest, resnet, sd_attn, mv, expand, out, groups, tail)
         except _PrefixDone as done:
             return done.skips
 
-    def _emit_body(self, b, u, h, skips, fulls, dest, resnet, sd_attn, mv, expand, out, groups):
+    def _emit_body(self, b, u, h, skips, fulls, dest, resnet, sd_attn, mv, expand, out, groups, tail=None):
         live_mv = None  # an MV-block output that is not a skip (freed once consumed)
+        compact = False    # True once the last multi-view block has dropped the views whose eps nobody reads (`tail`)
+        n_img_full = sum(groups)
         for lvl, blk in enumerate(u.down_blocks):
             has_attn = getattr(blk, "has_cross_attention", False)
             for i, r in enumerate(blk.resnets):
@@ -506,9 +545,13 @@ class MultiViewUNet(Denoiser, _PackMixin):
                     b.free(h)
                     h = h2
             if h.shape[1] <= 32 and h.shape[2] <= 32 and self.cfg.decoder_conditioning:
-                h2 = mv(self.cross_attn_blocks_decoder, lvl, f"mv_decoder.{lvl}", h)
+                # the last multi-view block in the last up block: only the kept views go on (see `tail`)
+                drop_here = (tail is not None and lvl == len(u.up_blocks) - 1 and blk.upsamplers is None
+                             and isinstance(self.cross_attn_blocks_decoder[lvl], SpatialTransformer3D))
+                h2 = mv(self.cross_attn_blocks_decoder, lvl, f"mv_decoder.{lvl}", h, **({"keep": tail} if drop_here else {}))
                 b.free(h)
                 h = h2
+                compact = drop_here
             if blk.upsamplers is not None:
                 for up in blk.upsamplers:
                     with b.scope(f"up{lvl}.upsample"):
@@ -518,7 +561,13 @@ class MultiViewUNet(Denoiser, _PackMixin):
         with b.scope("out"):
             g = u.conv_norm_out.emit(b, h, silu=True, name="conv_norm_out+silu")
             b.free(h)
-            eps = u.conv_out.emit(b, g, out_dtype=torch.float32, out=out, name="conv_out")
+            if compact:
+                eps_c = u.conv_out.emit(b, g, out_dtype=torch.float32, name="conv_out")
+                eps = out if out is not None else b.empty(n_img_full, *eps_c.shape[1:], dtype=torch.float32)
+                b.gather_rows(eps_c, eps, dst_index=tail[0], name="eps.scatter")
+                b.free(eps_c)
+            else:
+                eps = u.conv_out.emit(b, g, out_dtype=torch.float32, out=out, name="conv_out")
             b.free(g)
         return eps
 

@@ -255,7 +255,9 @@ class MVLDMPipeline:
                 dup = (n_cond, cond_img, ctx_rows, const_skips)
         bld = Builder(dev, dtype, record=True)
         with bld.scope("unet"):
-            den.emit(bld, unet_in, timesteps, groups, out=eps, dup=dup)
+            # (`tail`: only the target views' eps is read -- the last multi-view block and the output stage drop the context views)
+            tail = (tgt_rows, [v_c] * b + ([0] * b if use_cfg else [])) if v_c > 0 else None
+            den.emit(bld, unet_in, timesteps, groups, out=eps, dup=dup, tail=tail)
         bld.ddim_step(eps, x_state, x_state, cond_img, unc_img, self.cfg.cfg_scale, coef, step_ptr, unet_in,
                       clip_range=sch.clip_range)
         bld.ddim_advance(step_ptr, t_table, timesteps, tgt_rows)

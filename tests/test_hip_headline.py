@@ -197,6 +197,33 @@ def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
     assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 1.5e-2), e
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_tail_drop_equals_the_full_walk(models, monkeypatch, dtype):
+    """the context views' eps is never read by the sampler: the last multi-view block skips their queries in its 3-D attention and
+    runs the rest of the block + the output stage on the target views only (`MultiViewUNet.emit(tail=...)`).  The target views'
+    x_{t-1} must equal the plan that computes every view (`MVLDM_TAIL_DROP=0`)."""
+    M, m, _ = models
+    v_c, v_t, b = 1, 4, 2
+    ctx_lat, x_t, extr, intr = _inputs(v_c, v_t, b=b, seed=17)
+    outs, n_ops = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MVLDM_TAIL_DROP", mode)
+        monkeypatch.setenv("MVLDM_AUTOTUNE", "0")
+        pipe = _pipe(m)
+        with M.compute_dtype(dtype):
+            st = pipe._compile(b, v_c, v_t, 32, 32, dtype, 50)
+            pipe.load_inputs(st, ctx_lat, x_t, (extr[:, :v_c], intr[:, :v_c]), (extr[:, v_c:], intr[:, v_c:]))
+            st["plan"].replay()
+            st["plan"].replay()
+            outs[mode] = pipe._read_state(st, b, v_t).cpu()
+        n_ops[mode] = sum("keep_views" in mm.name or "eps.scatter" in mm.name for mm in st["plan"].meta)
+        pipe._plans.clear()
+    assert n_ops == {"1": 3, "0": 0}, n_ops
+    e = rel_err(outs["1"], outs["0"])
+    print(f"tail drop vs full walk [{dtype}], two DDIM steps: rel-err {e:.3e}")
+    assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 1.5e-2), e
+
+
 def test_plans_follow_weight_changes(models):
     """recorded plans hold pointers to PACKED copies of the weights: after `load_state_dict` (Lightning's
     load_from_checkpoint), an in-place copy or an optimizer step the next forward must use the new weights"""

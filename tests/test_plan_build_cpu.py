@@ -222,3 +222,34 @@ def test_shared_cfg_prefix_structure(cpu_record):
     f_full, f_shared = sum(mm.flops for mm in full.meta), sum(mm.flops for mm in shared.meta)
     prefix = sum(mm.flops for mm in full.meta[:next(i for i, mm in enumerate(full.meta) if "mv_encoder.0" in mm.name)])
     assert abs((f_full - f_shared) / (prefix * 8 / 18) - 1) < 1e-2          # (the time-embedding GEMMs in front are not shared)
+
+
+def test_tail_drop_structure(cpu_record):
+    """`MultiViewUNet.emit(tail=(keep_rows, drops))`: in the last multi-view block the 3-D attention attends the kept views' queries
+    only, everything behind it and the output stage run on the kept views (16 of 18 images), eps is scattered back"""
+    m = mvunet.MultiViewUNet(mvunet.MultiViewUNetCfg(pretrained_from="sd21"), 11, 4)
+    keep = torch.tensor([1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17], dtype=torch.int32)
+
+    def build(tail):
+        b = plan.Builder("cpu", torch.bfloat16, record=True, splitk_ws_bytes=1 << 20)
+        eps = m.emit(b, torch.zeros(18, 32, 32, 16, dtype=torch.bfloat16), torch.zeros(18, dtype=torch.int64), [5, 5, 4, 4],
+                     tail=(keep, [1, 1, 0, 0]) if tail else None)
+        assert eps.shape == (18, 32, 32, 4)
+        return b
+
+    full, cut = build(False), build(True)
+    names = [mm.name for mm in cut.meta]
+    i0 = next(i for i, n in enumerate(names) if "mv_decoder.3" in n and "keep_views" in n)
+    gathers = [mm.name.split("/")[-1] for op, mm in zip(cut.ops, cut.meta) if op.kind == L.OP_GATHER_ROWS]
+    assert gathers == ["keep_views", "keep_views.residual", "eps.scatter"], gathers
+    for i, (op, mm) in enumerate(zip(cut.ops, cut.meta)):
+        if op.kind == L.OP_IGEMM and "time" not in mm.name:
+            rows = op.u.igemm.n_img * op.u.igemm.h_out * op.u.igemm.w_out
+            if i > i0:
+                assert rows == 16 * 1024, (mm.name, rows)
+            elif "up3" in mm.name or "mv_decoder.3" in mm.name:
+                assert rows == 18 * 1024, (mm.name, rows)
+    att = [op for op, mm in zip(cut.ops, cut.meta) if op.kind == L.OP_ATTENTION and "mv_decoder.3" in mm.name and "attn1_3d" in mm.name]
+    assert len(att) == 1 and att[0].u.attention.max_q_len == 4 * 1024 and att[0].u.attention.n_seg == 4
+    f_full, f_cut = sum(mm.flops for mm in full.meta), sum(mm.flops for mm in cut.meta)
+    assert 0.985 < f_cut / f_full < 0.999
