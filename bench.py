@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--no-small-batch", action="store_true", help="skip the b in {1, 4, 16} latency lines")
     ap.add_argument("--no-parity", action="store_true", help="skip the 50-step f32-vs-bench-dtype drift measurement")
     ap.add_argument("--no-train-line", action="store_true", help="skip the short training-step measurement appended to the sampling line")
+    ap.add_argument("--no-full-walk", action="store_true", help="skip the 2-sample run without the exact sharing (`exact_sharing.full_walk`)")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the f16 run of the same workload (`alt_dtype` on a bf16 line)")
     ap.add_argument("--train", action="store_true",
                     help="measure the TRAINING step instead (BASELINE.json configs[3]): K optimizer steps of 2 micro-batches of "
@@ -471,6 +472,38 @@ def main():
                                 "ms_per_step": round(1e3 * alt_s, 3), "scenes_per_gpu": b,
                                 "parity_rel_err": {f"f16_vs_f32_latents_after_{args.ddim_steps}_steps": round(float((x_alt - x_hi).norm() / x_hi.norm()), 5)},
                                 "note": "same workload, plans and kernels as `value` with f16 activations / weights (fp32 accumulate)"}
+    out["exact_sharing"] = {
+        "enabled": os.environ.get("MVLDM_CFG_SHARE", "1") != "0",
+        "what": "algebraically exact reuse inside one sample(): the unconditional CFG pass re-submits the conditional pass's target views, so "
+                "the per-image layers in front of the first multi-view block run once per step for both (and once per sample for the "
+                "context views, whose inputs never change); the context views' eps is never read, so the last multi-view block and the "
+                "output stage run on the target views only.  Same values as the full walk (f32: 2e-6; tests/test_hip_headline.py); "
+                "`roofline` counts the FLOPs that are executed.  MVLDM_CFG_SHARE=0 MVLDM_TAIL_DROP=0 walks every image like the reference."}
+    if world == 1 and not args.no_full_walk and out["exact_sharing"]["enabled"]:
+        # ---- the same workload with every image walked through every layer (what the reference's two forwards compute): 2 samples
+        saved = {k: os.environ.get(k) for k in ("MVLDM_CFG_SHARE", "MVLDM_TAIL_DROP")}
+        os.environ["MVLDM_CFG_SHARE"], os.environ["MVLDM_TAIL_DROP"] = "0", "0"
+        kept = dict(pipe._plans)
+        pipe._plans.clear()
+        try:
+            pipe.sample(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                img_f, _ = pipe.sample(batch)
+            torch.cuda.synchronize()
+            fw_s = (time.perf_counter() - t0) / 2
+            assert torch.isfinite(img_f).all()
+            out["exact_sharing"]["full_walk"] = {"value": round(b * v_t / fw_s, 3), "unit": "views/s", "steps": 2, "warmup": 1,
+                                                 "ms_per_step": round(1e3 * fw_s, 3)}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            pipe._plans.clear()
+            pipe._plans.update(kept)
     if world == 1 and not args.no_train_line:
         # ---- the training step of the same path (BASELINE configs[3]; `python bench.py --train` is the full-length run).  Last
         # GPU work of the process: the fused AdamW updates the denoiser's weights in place.

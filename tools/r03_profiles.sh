@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p
 F=$(find $R/gpurun_out/pmc_fetch -name p_counter_collection.csv | head -1); W=$(find $R/gpurun_out/pmc_write -name p_counter_collection.csv | head -1)
 cp $R/profiles/pmc_traffic.json $R/gpurun_out/r03_pmc_traffic.json
 python3 tools/pmc_traffic.py $F $W $R/gpurun_out/r03_pmc_traffic.json 192 bf16_b64_res256 "round 3 (tools/r03_profiles.sh), the last 192 igemm dispatches of bench.py --unet-pass-only" > $R/gpurun_out/r03_pmc_traffic.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03 -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-small-batch --no-parity --no-train-line --no-alt-dtype > $R/gpurun_out/r03_prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03 -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-small-batch --no-parity --no-train-line --no-alt-dtype --no-full-walk > $R/gpurun_out/r03_prof_bench.log 2>&1
 S=$(find $R/gpurun_out/prof_r03 -name "bench_kernel_stats.csv" | head -1)
 cp $S $R/gpurun_out/r03_kernel_stats.csv
 # attention counters (d = 40 level-0 3-D block and d = 64 SD self-attention at 64 scenes), the weight-gradient forms
