@@ -28,6 +28,9 @@ def cpu_record(monkeypatch):
     L.load()
 
 
+_MODELS = {}
+
+
 def build_unet_plan(views, groups, h, dtype=torch.bfloat16, widths=None):
     with torch.device("meta"):
         pass
@@ -37,7 +40,9 @@ def build_unet_plan(views, groups, h, dtype=torch.bfloat16, widths=None):
         over = dict(block_out_channels=widths, attention_head_dim=tuple(max(1, c // 64) for c in widths))
         cfg = mvunet.MultiViewUNetCfg(autoencoder=mvunet.UNet2DModelCfg(block_out_channels=widths), pretrained_from="sd21",
                                       pretrained_overrides=over)
-    m = mvunet.MultiViewUNet(cfg, 11, 4)
+    m = _MODELS.get(widths)          # (building the 1.07 B-parameter module takes ~20 s: once per width set and test session)
+    if m is None:
+        m = _MODELS[widths] = mvunet.MultiViewUNet(cfg, 11, 4)
     b = plan.Builder("cpu", dtype, record=True, splitk_ws_bytes=1 << 20)
     x = torch.zeros(views, h, h, 16, dtype=dtype)
     ts = torch.zeros(views, dtype=torch.int64)
@@ -179,7 +184,7 @@ def test_shared_cfg_prefix_structure(cpu_record):
     """`MultiViewUNet.emit(dup=(n_src, src_rows))`: conv_in and the level-0 down block (2 resnets + 2 SD transformer blocks, all
     per-image work) run on the conditional images only, three row gathers fill the unconditional images' skip tensors right
     before the first multi-view block, everything after walks the full batch; executed FLOPs drop by the prefix's share"""
-    m = mvunet.MultiViewUNet(mvunet.MultiViewUNetCfg(pretrained_from="sd21"), 11, 4)
+    m, _, _ = build_unet_plan(1, [1], 8)
 
     def build(dup):
         b = plan.Builder("cpu", torch.bfloat16, record=True, splitk_ws_bytes=1 << 20)
@@ -227,7 +232,7 @@ def test_shared_cfg_prefix_structure(cpu_record):
 def test_tail_drop_structure(cpu_record):
     """`MultiViewUNet.emit(tail=(keep_rows, drops))`: in the last multi-view block the 3-D attention attends the kept views' queries
     only, everything behind it and the output stage run on the kept views (16 of 18 images), eps is scattered back"""
-    m = mvunet.MultiViewUNet(mvunet.MultiViewUNetCfg(pretrained_from="sd21"), 11, 4)
+    m, _, _ = build_unet_plan(1, [1], 8)
     keep = torch.tensor([1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17], dtype=torch.int32)
 
     def build(tail):
