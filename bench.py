@@ -137,7 +137,8 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
     from mv_ldm_amd.train import MVLDMTrainer
     torch.set_grad_enabled(False)
     b = args.scenes if args.scenes != 64 else 4
-    tr = MVLDMTrainer(den, vae, DDIMScheduler(clip_sample=False), dtype=dtype, world=world, rank=rank)
+    tr = MVLDMTrainer(den, vae, DDIMScheduler(clip_sample=False), dtype=dtype, world=world, rank=rank,
+                      graph=os.environ.get("MVLDM_TRAIN_GRAPH", "0") == "1")      # (A/B knob: the window plan as one hipGraph)
     g = torch.Generator().manual_seed(77 + rank)
     batch = synthetic_batch(b, 1, 3, args.res, 4000 + rank, dev)
     batch["target"]["image"] = torch.rand(b, 3, 3, args.res, args.res, generator=g).to(dev)
