@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 /* 3 (round 3): + mvldm_gather_rows, mvldm_ddpm_cfg_step, mvldm_ema_update; plan ops MVLDM_OP_PAR_BEGIN / _NEXT / _END and
- * MVLDM_OP_GATHER_ROWS; bits 8-9 of mvldm_wgrad_desc.accumulate select the weight-gradient kernel form.  Everything of version 2 is
+ * MVLDM_OP_GATHER_ROWS / MVLDM_OP_ATTN_MERGE; bits 8-9 of mvldm_wgrad_desc.accumulate select the weight-gradient kernel form.  Everything of version 2 is
  * unchanged (additive). */
 #define MVLDM_ABI_VERSION 3
 
@@ -351,6 +351,18 @@ int mvldm_ema_update(float* avg, const float* p, size_t n, float weight, mvldm_s
 int mvldm_gather_rows(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int n_rows, size_t row_bytes,
                       mvldm_stream_t stream);
 
+/* Merge two softmax-attention results of the SAME queries over DISJOINT key sets (the flash-attention combine): with the
+ * log-sum-exp outputs of mvldm_attention_fwd (log2 domain, [heads][lse_ld]) lse = log2(2^lse_a + 2^lse_b) and
+ * out = oa 2^(lse_a - lse) + ob 2^(lse_b - lse), per head.  Rows are addressed per image of `tokens` rows: image k of the merge reads
+ * rows a_img[k] * tokens + t of oa / lse_a, b_img[k] * tokens + t of ob / lse_b and writes row out_img[k] * tokens + t of out (out may
+ * be oa or ob when the image maps keep reads and writes of different k apart).  Used in the first multi-view block of the fused CFG
+ * forward: the target views' queries and keys are identical in the conditional and the unconditional pass there, so their scores over
+ * the target keys are computed once (the unconditional result) and the conditional result adds the context views' keys
+ * (mvdream/attention.py:174-205 evaluated once for both passes of diffusion_wrapper.py:435-441). */
+int mvldm_attention_merge(const void* oa, const float* lse_a, const void* ob, const float* lse_b, void* out, const int32_t* a_img,
+                          const int32_t* b_img, const int32_t* out_img, int n_img, int tokens, int heads, int head_dim, int ld_a, int ld_b,
+                          int ld_o, int lse_ld_a, int lse_ld_b, int dtype, mvldm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Plans: a whole forward (UNet walk, VAE decoder, DDIM step) as a flat list of the ops above with
  * all pointers resolved -- built once by the host (mv_ldm_amd/plan.py), executed here without
@@ -369,7 +381,7 @@ enum {
      * hipGraph (the four sub-pixel phase convs of an upsampler, a resnet's 1x1 shortcut beside its main chain: what fills the chip at
      * one or two scenes).  mvldm_op_run and mvldm_plan_profile treat them as no-ops (serial order is always valid). */
     MVLDM_OP_PAR_BEGIN, MVLDM_OP_PAR_NEXT, MVLDM_OP_PAR_END,
-    MVLDM_OP_GATHER_ROWS
+    MVLDM_OP_GATHER_ROWS, MVLDM_OP_ATTN_MERGE
 };
 
 typedef struct mvldm_op {
@@ -415,6 +427,8 @@ typedef struct mvldm_op {
         struct { void* dst; size_t bytes; } fill;
         struct { const void* src; void* dst; size_t bytes; } memcpy_;
         struct { const void* src; void* dst; const int32_t* src_index; const int32_t* dst_index; size_t row_bytes; int32_t n_rows; } gather;
+        struct { const void* oa; const void* ob; void* out; const float* lse_a; const float* lse_b; const int32_t* a_img; const int32_t* b_img;
+                 const int32_t* out_img; int32_t n_img, tokens, heads, head_dim, ld_a, ld_b, ld_o, lse_ld_a, lse_ld_b, dtype; } attn_merge;
     } u;
 } mvldm_op;
 

@@ -21,7 +21,7 @@ GN_MAX_CHUNKS = 32
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_TIMESTEP_EMBED, OP_ELTWISE, OP_DDIM_STEP, OP_DDIM_ADVANCE,
  OP_NCHW_TO_NHWC, OP_NHWC_TO_NCHW, OP_MEMCPY, OP_RAY_ENCODE, OP_POSTERIOR_SAMPLE,
  OP_WGRAD, OP_ATTENTION_BWD, OP_GROUPNORM_BWD, OP_LAYERNORM_BWD, OP_COLSUM, OP_TRAIN_ELTWISE, OP_POOL2X2, OP_ZERO_INSERT,
- OP_ADD_NOISE, OP_MSE_LOSS, OP_FILL_ZERO, OP_PAR_BEGIN, OP_PAR_NEXT, OP_PAR_END, OP_GATHER_ROWS) = range(1, 29)
+ OP_ADD_NOISE, OP_MSE_LOSS, OP_FILL_ZERO, OP_PAR_BEGIN, OP_PAR_NEXT, OP_PAR_END, OP_GATHER_ROWS, OP_ATTN_MERGE) = range(1, 30)
 TE_SILU_BWD, TE_ADD, TE_GEGLU_FWD, TE_GEGLU_BWD, TE_GELU_BWD = 0, 1, 2, 3, 4
 
 vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -92,6 +92,12 @@ class _Memcpy(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("bytes", sz)]
 
 
+class _AttnMerge(C.Structure):
+    _fields_ = [("oa", vp), ("ob", vp), ("out", vp), ("lse_a", vp), ("lse_b", vp), ("a_img", vp), ("b_img", vp), ("out_img", vp),
+                ("n_img", i32), ("tokens", i32), ("heads", i32), ("head_dim", i32), ("ld_a", i32), ("ld_b", i32), ("ld_o", i32),
+                ("lse_ld_a", i32), ("lse_ld_b", i32), ("dtype", i32)]
+
+
 class _Gather(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("src_index", vp), ("dst_index", vp), ("row_bytes", sz), ("n_rows", i32)]
 
@@ -155,7 +161,7 @@ class _Fill(C.Structure):
 class _OpUnion(C.Union):
     _fields_ = [("igemm", IgemmDesc), ("groupnorm", _GroupNorm), ("layernorm", _LayerNorm), ("attention", _Attention),
                 ("temb", _Temb), ("eltwise", _Eltwise), ("ddim", _Ddim), ("advance", _Advance), ("layout", _Layout),
-                ("memcpy_", _Memcpy), ("gather", _Gather), ("rays", _Rays), ("posterior", _Posterior),
+                ("memcpy_", _Memcpy), ("gather", _Gather), ("attn_merge", _AttnMerge), ("rays", _Rays), ("posterior", _Posterior),
                 ("wgrad", WgradDesc), ("attention_bwd", AttnBwdDesc), ("groupnorm_bwd", _GroupNormBwd),
                 ("layernorm_bwd", _LayerNormBwd), ("colsum", _Colsum), ("train_eltwise", _TrainEltwise), ("resample", _Resample),
                 ("add_noise", _AddNoise), ("mse", _Mse), ("fill", _Fill)]
@@ -193,6 +199,7 @@ SIGNATURES = {
     "mvldm_ddim_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
     "mvldm_ddim_advance": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "mvldm_gather_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, sz, vp]),
+    "mvldm_attention_merge": (C.c_int, [vp] * 8 + [C.c_int] * 10 + [vp]),
     "mvldm_ddpm_cfg_step": (C.c_int, [vp, vp, vp, vp, vp, sz, f32, vp, f32, vp]),
     "mvldm_ema_update": (C.c_int, [vp, vp, sz, f32, vp]),
     "mvldm_nchw_to_nhwc": (C.c_int, [vp, vp] + [C.c_int] * 6 + [f32, f32, vp, vp]),

@@ -792,6 +792,51 @@ int attention_run(const void* q, const void* k, const void* v, void* out, int ld
     });
 }
 
+// ---- combine of two attention results over disjoint key sets (see mvldm_attention_merge) -------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const T* __restrict__ oa, const float* __restrict__ lse_a, const T* __restrict__ ob,
+                                                         const float* __restrict__ lse_b, T* __restrict__ out, const int32_t* __restrict__ a_img,
+                                                         const int32_t* __restrict__ b_img, const int32_t* __restrict__ out_img, int n_img, int tokens,
+                                                         int heads, int d, int ld_a, int ld_b, int ld_o, int lla, int llb) {
+    constexpr int EPC = Elt<T>::EPC;
+    const int cpr = heads * d / EPC;                     // chunks per row
+    const size_t total = (size_t)n_img * tokens * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % cpr);
+        const size_t rt = i / cpr;
+        const int t = (int)(rt % tokens), k = (int)(rt / tokens);
+        const size_t ra = (size_t)a_img[k] * tokens + t, rb = (size_t)b_img[k] * tokens + t, ro = (size_t)out_img[k] * tokens + t;
+        const int head = c * EPC / d;
+        const float la = lse_a[(size_t)head * lla + ra], lb = lse_b[(size_t)head * llb + rb];
+        const float mx = fmaxf(la, lb);
+        const float ea = __builtin_amdgcn_exp2f(la - mx), eb = __builtin_amdgcn_exp2f(lb - mx);
+        const float inv = 1.0f / (ea + eb);
+        const float wa = ea * inv, wb = eb * inv;
+        const Chunk<T> va = load_chunk<T>(oa + ra * ld_a + c * EPC), vb = load_chunk<T>(ob + rb * ld_b + c * EPC);
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, va.get(e) * wa + vb.get(e) * wb);
+        store_chunk<T>(out + ro * ld_o + c * EPC, o);
+    }
+}
+
+int attention_merge_run(const void* oa, const float* lse_a, const void* ob, const float* lse_b, void* out, const int32_t* a_img,
+                        const int32_t* b_img, const int32_t* out_img, int n_img, int tokens, int heads, int head_dim, int ld_a, int ld_b,
+                        int ld_o, int lse_ld_a, int lse_ld_b, int dtype, hipStream_t s) {
+    const int epc = dtype == MVLDM_F32 ? 4 : 8;
+    if (n_img == 0 || tokens == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(oa && ob && out && lse_a && lse_b && a_img && b_img && out_img, "attention_merge: null pointer");
+    MVLDM_REQUIRE(head_dim % epc == 0 && ld_a % epc == 0 && ld_b % epc == 0 && ld_o % epc == 0, "attention_merge: 16-byte alignment");
+    const size_t total = (size_t)n_img * tokens * (heads * head_dim / epc);
+    return dispatch_dtype(dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(attn_merge_kernel<T>, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, reinterpret_cast<const T*>(oa),
+                           lse_a, reinterpret_cast<const T*>(ob), lse_b, reinterpret_cast<T*>(out), a_img, b_img, out_img, n_img, tokens, heads, head_dim,
+                           ld_a, ld_b, ld_o, lse_ld_a, lse_ld_b);
+        return check_launch();
+    });
+}
+
 }  // namespace mvldm
 
 extern "C" int mvldm_attention_fwd(const void* q, const void* k, const void* v, void* out, int ld_q, int ld_k, int ld_v,
@@ -799,4 +844,10 @@ extern "C" int mvldm_attention_fwd(const void* q, const void* k, const void* v, 
                                    float scale, int dtype, float* lse, int lse_ld, mvldm_stream_t stream) {
     return mvldm::attention_run(q, k, v, out, ld_q, ld_k, ld_v, ld_o, heads, head_dim, seg, n_seg, max_q_len, scale,
                                 dtype, lse, lse_ld, (hipStream_t)stream);
+}
+extern "C" int mvldm_attention_merge(const void* oa, const float* lse_a, const void* ob, const float* lse_b, void* out, const int32_t* a_img,
+                                     const int32_t* b_img, const int32_t* out_img, int n_img, int tokens, int heads, int head_dim, int ld_a,
+                                     int ld_b, int ld_o, int lse_ld_a, int lse_ld_b, int dtype, mvldm_stream_t stream) {
+    return mvldm::attention_merge_run(oa, lse_a, ob, lse_b, out, a_img, b_img, out_img, n_img, tokens, heads, head_dim, ld_a, ld_b, ld_o, lse_ld_a,
+                               lse_ld_b, dtype, (hipStream_t)stream);
 }

@@ -44,6 +44,9 @@ int mse_run(const float* pred, const float* noise, const int32_t* tgt_img, int n
 int to_nchw_run(const void* src, float* dst, int n_img, int c, int hw, int src_c, int src_c_off, int src_dtype, float scale,
                 float shift, int clamp01, hipStream_t s);
 int gather_rows_run(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int n_rows, size_t row_bytes, hipStream_t s);
+int attention_merge_run(const void* oa, const float* lse_a, const void* ob, const float* lse_b, void* out, const int32_t* a_img,
+                        const int32_t* b_img, const int32_t* out_img, int n_img, int tokens, int heads, int head_dim, int ld_a, int ld_b,
+                        int ld_o, int lse_ld_a, int lse_ld_b, int dtype, hipStream_t s);
 
 static int run_op(const mvldm_op& op, hipStream_t s) {
     switch (op.kind) {
@@ -150,6 +153,11 @@ static int run_op(const mvldm_op& op, hipStream_t s) {
         case MVLDM_OP_GATHER_ROWS: {
             const auto& g = op.u.gather;
             return gather_rows_run(g.src, g.dst, g.src_index, g.dst_index, g.n_rows, g.row_bytes, s);
+        }
+        case MVLDM_OP_ATTN_MERGE: {
+            const auto& m = op.u.attn_merge;
+            return attention_merge_run(m.oa, m.lse_a, m.ob, m.lse_b, m.out, m.a_img, m.b_img, m.out_img, m.n_img, m.tokens, m.heads, m.head_dim,
+                                       m.ld_a, m.ld_b, m.ld_o, m.lse_ld_a, m.lse_ld_b, m.dtype, s);
         }
         case MVLDM_OP_PAR_BEGIN:
         case MVLDM_OP_PAR_NEXT:

@@ -111,14 +111,17 @@ class BasicTransformerBlock3D(nn.Module):
         self.norm2 = LayerNorm(dim)
         self.norm3 = LayerNorm(dim)
 
-    def emit(self, b: Builder, hs, groups: Sequence[int], tokens: int, keep=None):
+    def emit(self, b: Builder, hs, groups: Sequence[int], tokens: int, keep=None, pair=None):
         """`keep = (keep_rows, drops)`: only the views `keep_rows` (device int32 image rows; per group the first `drops[g]` views are
         dropped) are needed downstream -- the last multi-view block of the sampler, whose context-view outputs nothing reads: the
         3-D attention skips the dropped views' queries (their keys / values still serve the others) and everything behind it runs
         on the kept views, compacted.  Returns the compact token matrix [len(keep_rows) * tokens, C] then."""
         scene_lens = [g * tokens for g in groups]
         n1 = self.norm1.emit(b, hs, name="norm1")
-        if keep is None:
+        if pair is not None:
+            n_views = sum(groups)
+            h1 = self._emit_attn3d_pair(b, n1, hs, groups, tokens, pair)
+        elif keep is None:
             n_views = sum(groups)
             h1 = self.attn1.emit_self(b, n1, hs, _segments(b, scene_lens), scene_lens, name="attn1_3d")
         else:
@@ -148,6 +151,61 @@ class BasicTransformerBlock3D(nn.Module):
         return out
 
 
+def _emit_attn3d_pair(self, b: Builder, n1, hs, groups, tokens, pair):
+    """3-D attention of the FIRST multi-view block of the fused CFG forward.  `pair = (n_cond, cond_img, unc_img)`: the groups are
+    [conditional scenes (context + target views)] + [unconditional scenes (the same target views)] and -- the layers in front
+    being per-image -- the target views' rows hold identical features in both (MultiViewUNet.emit, `dup`).  Their queries and
+    keys / values are therefore identical too, and the conditional softmax over {context, target} keys is the unconditional
+    one over {target} keys extended by the context keys:
+        launch 1:  unconditional scenes as usual (-> final rows + lse)   and   context queries x all keys of their scene (final rows)
+        launch 2:  conditional target queries x the context views' keys only (-> partial rows + lse)
+        merge:     conditional target rows = combine(unconditional rows, partial rows)       (mvldm_attention_merge)
+    25 instead of 41 view x view blocks of scores at 1 context + 4 target views."""
+    a1 = self.attn1
+    n_cond, cond_img, unc_img = pair
+    C = a1.inner
+    half = len(groups) // 2
+    cond_g, unc_g = list(groups[:half]), list(groups[half:])
+    assert sum(cond_g) == n_cond and len(cond_g) == len(unc_g) and all(c > u for c, u in zip(cond_g, unc_g))
+    qkv = b.linear(n1, a1._packed_cat(b.dtype, [a1.to_q, a1.to_k, a1.to_v]), a1._bias_cat([a1.to_q, a1.to_k, a1.to_v]), name="attn1_3d.to_qkv")
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    m_full = qkv.shape[0]
+    a = b.empty(m_full, C, dtype=qkv.dtype)
+    lse1 = b.empty(a1.heads, m_full, dtype=torch.float32)
+    seg1, q1, kv1, seg2, q2, kv2 = [], [], [], [], [], []
+    row0 = 0
+    for c, u in zip(cond_g, unc_g):                  # conditional scenes: context views first, then the targets
+        vc = c - u
+        seg1.append([row0, vc * tokens, row0, c * tokens])                      # context queries x all keys
+        q1.append(vc * tokens); kv1.append(c * tokens)
+        seg2.append([row0 + vc * tokens, u * tokens, row0, vc * tokens])        # target queries x context keys
+        q2.append(u * tokens); kv2.append(vc * tokens)
+        row0 += c * tokens
+    for u in unc_g:                                  # unconditional scenes
+        seg1.append([row0, u * tokens, row0, u * tokens])
+        q1.append(u * tokens); kv1.append(u * tokens)
+        row0 += u * tokens
+    seg1_t = torch.tensor(seg1, dtype=torch.int32, device=b.device)
+    seg2_t = torch.tensor(seg2, dtype=torch.int32, device=b.device)
+    b.keep.extend([seg1_t, seg2_t])
+    b.attention(q, k, v, a1.heads, a1.dim_head, seg1_t, q1, kv1, name="attn1_3d.sdpa", lse=lse1, out=a)
+    n_cond_rows = n_cond * tokens
+    part = b.empty(n_cond_rows, C, dtype=qkv.dtype)
+    lse2 = b.empty(a1.heads, n_cond_rows, dtype=torch.float32)
+    b.attention(q, k, v, a1.heads, a1.dim_head, seg2_t, q2, kv2, name="attn1_3d.sdpa.ctx_keys", lse=lse2, out=part)
+    b.free(qkv)
+    b.attention_merge(a, lse1, part, lse2, a, unc_img, cond_img, cond_img, tokens, a1.heads, a1.dim_head, name="attn1_3d.merge")
+    b.free(part)
+    b.free(lse1)
+    b.free(lse2)
+    out = b.linear(a, a1.to_out[0].packed(b.dtype), a1.out_bias(None), residual=hs, name="attn1_3d.to_out")
+    b.free(a)
+    return out
+
+
+BasicTransformerBlock3D._emit_attn3d_pair = _emit_attn3d_pair
+
+
 class SpatialTransformer3D(nn.Module):
     """mvdream/attention.py:371-439 (`use_linear=False`).  `proj_out` is zero-initialised like the
     reference's `zero_module` (:407-411)."""
@@ -164,7 +222,7 @@ class SpatialTransformer3D(nn.Module):
         nn.init.zeros_(self.proj_out.weight)
         nn.init.zeros_(self.proj_out.bias)
 
-    def emit(self, b: Builder, x, groups: Sequence[int], keep=None):
+    def emit(self, b: Builder, x, groups: Sequence[int], keep=None, pair=None):
         """x: NHWC [sum(groups), h, w, C]; `groups` = number of views of each scene.  `keep`: see BasicTransformerBlock3D.emit --
         the result then holds the kept views only, [len(keep_rows), h, w, C]."""
         n, h, w, c = x.shape
@@ -175,7 +233,7 @@ class SpatialTransformer3D(nn.Module):
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             with b.scope(f"transformer_blocks.{i}"):
-                nxt = blk.emit(b, hs, groups, h * w, keep=keep if i == last else None)
+                nxt = blk.emit(b, hs, groups, h * w, keep=keep if i == last else None, pair=pair if i == 0 else None)
             b.free(hs)
             hs = nxt
         res, n_out = x, n
@@ -459,7 +517,14 @@ class MultiViewUNet(Denoiser, _PackMixin):
                 return fulls[id(h)]
 
         def mv(blocks, idx, name, h, **kw):
+            was_shared = shared
             h = expand(h)
+            if (was_shared and isinstance(blocks[idx], SpatialTransformer3D) and len(groups) % 2 == 0
+                    and os.environ.get("MVLDM_CFG_SHARE_ATTN", "1") != "0"):
+                # the first multi-view block: the target views' rows are still identical in both passes -- share their scores
+                unc_img = torch.arange(n_src, n_img, dtype=torch.int32, device=b.device)
+                b.keep.append(unc_img)
+                kw = dict(kw, pair=(n_src, dup[1], unc_img))
             with b.scope(name):
                 return blocks[idx].emit(b, h, groups, **kw)
 

@@ -297,10 +297,12 @@ class Builder:
         self._emit(op, name, 0.0, 2.0 * y.numel() * y.element_size(), (x, y, gamma, beta))
         return y
 
-    def attention(self, q, k, v, heads, head_dim, seg, q_lens, kv_lens, scale=None, name="attention", lse=None):
-        """q/k/v: 2-D views with unit column stride (may be slices of one fused projection)."""
+    def attention(self, q, k, v, heads, head_dim, seg, q_lens, kv_lens, scale=None, name="attention", lse=None, out=None):
+        """q/k/v: 2-D views with unit column stride (may be slices of one fused projection).  `out`: existing [rows, heads * head_dim]
+        buffer (rows are addressed by the segments' query rows); `lse`: fp32 [heads, rows] log-sum-exp output (log2 domain)."""
         assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
-        out = self.empty(q.shape[0], heads * head_dim, dtype=q.dtype)
+        if out is None:
+            out = self.empty(q.shape[0], heads * head_dim, dtype=q.dtype)
         op = L.Op()
         op.kind = L.OP_ATTENTION
         a = op.u.attention
@@ -314,6 +316,19 @@ class Builder:
         nbytes = (sum(q_lens) * 2 + sum(kv_lens) * 2) * heads * head_dim * es
         self._emit(op, name, 4.0 * pairs * heads * head_dim, nbytes, (q, k, v, out, seg, lse))
         return out
+
+    def attention_merge(self, oa, lse_a, ob, lse_b, out, a_img, b_img, out_img, tokens, heads, head_dim, name="attention_merge"):
+        """combine two attention results of the same queries over disjoint key sets (mvldm_attention_merge), per image of `tokens` rows"""
+        n = a_img.numel()
+        assert b_img.numel() == n and out_img.numel() == n and all(i.dtype == torch.int32 for i in (a_img, b_img, out_img))
+        assert lse_a.dtype == torch.float32 and lse_b.dtype == torch.float32 and oa.dtype == ob.dtype == out.dtype
+        op = L.Op()
+        op.kind = L.OP_ATTN_MERGE
+        m = op.u.attn_merge
+        m.oa, m.ob, m.out, m.lse_a, m.lse_b, m.a_img, m.b_img, m.out_img = ptr(oa), ptr(ob), ptr(out), ptr(lse_a), ptr(lse_b), ptr(a_img), ptr(b_img), ptr(out_img)
+        m.n_img, m.tokens, m.heads, m.head_dim = n, tokens, heads, head_dim
+        m.ld_a, m.ld_b, m.ld_o, m.lse_ld_a, m.lse_ld_b, m.dtype = oa.stride(0), ob.stride(0), out.stride(0), lse_a.stride(0), lse_b.stride(0), dt(oa)
+        self._emit(op, name, 0.0, 3.0 * n * tokens * heads * head_dim * oa.element_size(), (oa, lse_a, ob, lse_b, out, a_img, b_img, out_img))
 
     def timestep_embed(self, timesteps, freqs, dim, flip, dtype, name="time_proj"):
         out = self.empty(timesteps.numel(), dim, dtype=dtype)

@@ -195,7 +195,11 @@ def test_shared_cfg_prefix_structure(cpu_record):
         return b
 
     full, shared = build(False), build(True)
-    assert len(shared.meta) == len(full.meta) + 3
+    assert len(shared.meta) == len(full.meta) + 3 + 2          # 3 gathers; the first 3-D attention becomes 2 launches + a merge
+    att = [(op, mm) for op, mm in zip(shared.ops, shared.meta) if "mv_encoder.0" in mm.name and "attn1_3d" in mm.name and op.kind in (L.OP_ATTENTION, L.OP_ATTN_MERGE)]
+    assert [mm.name.split("/")[-1] for _, mm in att] == ["attn1_3d.sdpa", "attn1_3d.sdpa.ctx_keys", "attn1_3d.merge"]
+    full_att = next(mm for mm in full.meta if "mv_encoder.0" in mm.name and mm.name.endswith("attn1_3d.sdpa"))
+    assert abs(sum(mm.flops for _, mm in att) / full_att.flops - 25.0 / 41.0) < 1e-6          # view x view score blocks: 25 of 41
     gathers = [(op, mm) for op, mm in zip(shared.ops, shared.meta) if op.kind == L.OP_GATHER_ROWS]
     assert [mm.name for _, mm in gathers] == ["unet/cfg_share/skip0", "unet/cfg_share/skip1", "unet/cfg_share/skip2"] or \
         [mm.name.split("/")[-1] for _, mm in gathers] == ["skip0", "skip1", "skip2"]
@@ -226,7 +230,8 @@ def test_shared_cfg_prefix_structure(cpu_record):
             assert op.u.igemm.n_img * op.u.igemm.h_out * op.u.igemm.w_out == 8 * 1024, mm.name      # one copy of every target view
     f_full, f_shared = sum(mm.flops for mm in full.meta), sum(mm.flops for mm in shared.meta)
     prefix = sum(mm.flops for mm in full.meta[:next(i for i, mm in enumerate(full.meta) if "mv_encoder.0" in mm.name)])
-    assert abs((f_full - f_shared) / (prefix * 8 / 18) - 1) < 1e-2          # (the time-embedding GEMMs in front are not shared)
+    # (the time-embedding GEMMs in front are not shared; the first 3-D attention drops 16 of its 41 view x view blocks)
+    assert abs((f_full - f_shared) / (prefix * 8 / 18 + full_att.flops * 16 / 41) - 1) < 1e-2
 
 
 def test_tail_drop_structure(cpu_record):
