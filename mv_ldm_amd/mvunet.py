@@ -157,8 +157,9 @@ def _emit_attn3d_pair(self, b: Builder, n1, hs, groups, tokens, pair):
     being per-image -- the target views' rows hold identical features in both (MultiViewUNet.emit, `dup`).  Their queries and
     keys / values are therefore identical too, and the conditional softmax over {context, target} keys is the unconditional
     one over {target} keys extended by the context keys:
-        launch 1:  unconditional scenes as usual (-> final rows + lse)   and   context queries x all keys of their scene (final rows)
-        launch 2:  conditional target queries x the context views' keys only (-> partial rows + lse)
+        launch 1:  unconditional scenes as usual (-> final rows + lse)
+        launch 2:  context queries x all keys of their scene (final rows)
+        launch 3:  conditional target queries x the context views' keys only (-> partial rows + lse)
         merge:     conditional target rows = combine(unconditional rows, partial rows)       (mvldm_attention_merge)
     25 instead of 41 view x view blocks of scores at 1 context + 4 target views."""
     a1 = self.attn1
@@ -172,12 +173,12 @@ def _emit_attn3d_pair(self, b: Builder, n1, hs, groups, tokens, pair):
     m_full = qkv.shape[0]
     a = b.empty(m_full, C, dtype=qkv.dtype)
     lse1 = b.empty(a1.heads, m_full, dtype=torch.float32)
-    seg1, q1, kv1, seg2, q2, kv2 = [], [], [], [], [], []
+    seg0, q0, kv0, seg1, q1, kv1, seg2, q2, kv2 = [], [], [], [], [], [], [], [], []
     row0 = 0
     for c, u in zip(cond_g, unc_g):                  # conditional scenes: context views first, then the targets
         vc = c - u
-        seg1.append([row0, vc * tokens, row0, c * tokens])                      # context queries x all keys
-        q1.append(vc * tokens); kv1.append(c * tokens)
+        seg0.append([row0, vc * tokens, row0, c * tokens])                      # context queries x all keys
+        q0.append(vc * tokens); kv0.append(c * tokens)
         seg2.append([row0 + vc * tokens, u * tokens, row0, vc * tokens])        # target queries x context keys
         q2.append(u * tokens); kv2.append(vc * tokens)
         row0 += c * tokens
@@ -185,10 +186,12 @@ def _emit_attn3d_pair(self, b: Builder, n1, hs, groups, tokens, pair):
         seg1.append([row0, u * tokens, row0, u * tokens])
         q1.append(u * tokens); kv1.append(u * tokens)
         row0 += u * tokens
-    seg1_t = torch.tensor(seg1, dtype=torch.int32, device=b.device)
-    seg2_t = torch.tensor(seg2, dtype=torch.int32, device=b.device)
-    b.keep.extend([seg1_t, seg2_t])
+    seg0_t, seg1_t, seg2_t = (torch.tensor(sg, dtype=torch.int32, device=b.device) for sg in (seg0, seg1, seg2))
+    b.keep.extend([seg0_t, seg1_t, seg2_t])
     b.attention(q, k, v, a1.heads, a1.dim_head, seg1_t, q1, kv1, name="attn1_3d.sdpa", lse=lse1, out=a)
+    # (its own launch: a few query tiles per (head, scene) -- the short-sequence launch geometry keeps them on the XCD whose L2 holds
+    #  that scene's K / V; inside the long launch they ran at 0.35 ms per view x view block instead of 0.15)
+    b.attention(q, k, v, a1.heads, a1.dim_head, seg0_t, q0, kv0, name="attn1_3d.sdpa.ctx_queries", out=a)
     n_cond_rows = n_cond * tokens
     part = b.empty(n_cond_rows, C, dtype=qkv.dtype)
     lse2 = b.empty(a1.heads, n_cond_rows, dtype=torch.float32)

@@ -195,9 +195,9 @@ def test_shared_cfg_prefix_structure(cpu_record):
         return b
 
     full, shared = build(False), build(True)
-    assert len(shared.meta) == len(full.meta) + 3 + 2          # 3 gathers; the first 3-D attention becomes 2 launches + a merge
+    assert len(shared.meta) == len(full.meta) + 3 + 3          # 3 gathers; the first 3-D attention becomes 3 launches + a merge
     att = [(op, mm) for op, mm in zip(shared.ops, shared.meta) if "mv_encoder.0" in mm.name and "attn1_3d" in mm.name and op.kind in (L.OP_ATTENTION, L.OP_ATTN_MERGE)]
-    assert [mm.name.split("/")[-1] for _, mm in att] == ["attn1_3d.sdpa", "attn1_3d.sdpa.ctx_keys", "attn1_3d.merge"]
+    assert [mm.name.split("/")[-1] for _, mm in att] == ["attn1_3d.sdpa", "attn1_3d.sdpa.ctx_queries", "attn1_3d.sdpa.ctx_keys", "attn1_3d.merge"]
     full_att = next(mm for mm in full.meta if "mv_encoder.0" in mm.name and mm.name.endswith("attn1_3d.sdpa"))
     assert abs(sum(mm.flops for _, mm in att) / full_att.flops - 25.0 / 41.0) < 1e-6          # view x view score blocks: 25 of 41
     gathers = [(op, mm) for op, mm in zip(shared.ops, shared.meta) if op.kind == L.OP_GATHER_ROWS]
