@@ -367,7 +367,7 @@ def main():
                            "share_of_step_time": round(ig[0] / tot_ms, 3),
                            "flops_per_pass": ig[1], "step_ms_eager_sum": round(tot_ms, 3)}
         names = {OP_IGEMM: "igemm", OP_ATTENTION: "attention", OP_GROUPNORM: "groupnorm", OP_LAYERNORM: "layernorm",
-                 L_.OP_GATHER_ROWS: "cfg_share_gather", L_.OP_DDIM_STEP: "ddim_cfg_step", L_.OP_DDIM_ADVANCE: "ddim_advance",
+                 L_.OP_GATHER_ROWS: "cfg_share_gather", L_.OP_ATTN_MERGE: "attention_merge", L_.OP_DDIM_STEP: "ddim_cfg_step", L_.OP_DDIM_ADVANCE: "ddim_advance",
                  L_.OP_TIMESTEP_EMBED: "timestep_embed"}
         out["kernel_breakdown_ms"] = {names.get(k, f"op{k}"): round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         # the other kernel families of the step, each against the roof that bounds it (same HIP-event timings)
