@@ -106,6 +106,26 @@ int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksiz
                       int k_pad, int geglu, int k_order, int dst_dtype, int transpose, int c_off, int n_rows,
                       mvldm_stream_t stream);
 
+/* The same transform for MANY weights in one launch (round 3): after an optimizer step the training path re-packs every
+ * trained weight (forward + data-gradient packs, ~380 of them) -- as one launch per pack these are latency-bound (7 ms for
+ * 7.4 GB).  A job is the argument list of mvldm_pack_weight(); mvldm_pack_job_prepare() validates it and fills `kind`
+ * and `blocks` (host side, no GPU work).  The caller sets `block0` = exclusive prefix sum of `blocks` over the job list,
+ * copies the list to the device and passes it with `total_blocks` = the sum.  Output bytes are identical to n_jobs calls
+ * of mvldm_pack_weight().  replaces: nothing in the reference (torch keeps one weight layout; its optimizer step is the
+ * last touch). */
+typedef struct mvldm_pack_job {
+    const float* src; void* dst;
+    int n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu, k_order, transpose, c_off, n_rows;
+    int kind;        /* filled by mvldm_pack_job_prepare: which packer body */
+    int blocks;      /* filled by mvldm_pack_job_prepare: workgroups of this job */
+    int block0;      /* caller: first workgroup of this job inside the batched launch */
+} mvldm_pack_job;
+int mvldm_pack_job_prepare(mvldm_pack_job* job /* host */, int dst_dtype);
+/* `block_job` (device, total_blocks int32, may be NULL): the job index of every workgroup -- one load instead of a binary
+ * search over the job list per workgroup (a workgroup moves only 4-18 KB). */
+int mvldm_pack_weight_batch(const mvldm_pack_job* jobs /* device */, int n_jobs, const int32_t* block_job, int total_blocks,
+                            int dst_dtype, mvldm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.   replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D
  * (norm1/norm2 + nonlinearity), conv_norm_out + conv_act (mvunet.py:203-204), Transformer2DModel.norm

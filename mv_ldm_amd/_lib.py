@@ -102,6 +102,13 @@ class _Gather(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("src_index", vp), ("dst_index", vp), ("row_bytes", sz), ("n_rows", i32)]
 
 
+class PackJob(C.Structure):
+    """mvldm_pack_job: the arguments of one mvldm_pack_weight() call as a row of the batched re-pack's job list"""
+    _fields_ = [("src", vp), ("dst", vp), ("n_out", i32), ("c_in", i32), ("ksize", i32), ("c_pad", i32), ("n_pad", i32), ("k_pad", i32),
+                ("geglu", i32), ("k_order", i32), ("transpose", i32), ("c_off", i32), ("n_rows", i32), ("kind", i32), ("blocks", i32),
+                ("block0", i32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("src0", vp), ("src1", vp), ("dy", vp), ("grad", vp), ("workspace", vp), ("workspace_bytes", sz),
                 ("c0", i32), ("c1", i32), ("c_in", i32),
@@ -179,6 +186,8 @@ SIGNATURES = {
     "mvldm_igemm_fwd": (C.c_int, [C.POINTER(IgemmDesc), vp]),
     "mvldm_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
     "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
+    "mvldm_pack_job_prepare": (C.c_int, [C.POINTER(PackJob), C.c_int]),
+    "mvldm_pack_weight_batch": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp, vp]),
     "mvldm_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
     "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp, C.c_int, vp]),

@@ -1113,105 +1113,145 @@ template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce
 }
 
 // ---- weight packing -------------------------------------------------------------------------------
+// One kernel for every pack: a workgroup executes the body its job's `kind` names on its block index inside the job.  A single
+// pack (mvldm_pack_weight) passes its job by value; the batched launch (mvldm_pack_weight_batch) finds the job of a workgroup in
+// the device job list by its `block0`.  Same bodies, hence the same bytes out either way.
+enum { PACK_GENERIC = 0, PACK_FWD_K1 = 1, PACK_FWD_K3 = 2, PACK_T_K3 = 3, PACK_T_K1 = 4 };
+
+// generic: one thread per packed element, any dtype / K order (grid-stride over the job's `nb` workgroups)
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_out,
-                                                          int c_in, int ksize, int c_pad, int n_pad, int k_pad, int geglu, int korder, int bk,
-                                                          int transpose, int c_off, int n_rows) {
-    const size_t total = (size_t)n_pad * k_pad;
-    const int taps = ksize * ksize;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int np = (int)(idx / k_pad), k = (int)(idx - (size_t)np * k_pad);
+__device__ __forceinline__ void pack_generic_body(const mvldm_pack_job& j, int bx, int nb) {
+    T* __restrict__ dst = reinterpret_cast<T*>(j.dst);
+    const float* __restrict__ src = j.src;
+    const int bk = sizeof(T) == 4 ? 32 : 64;
+    const size_t total = (size_t)j.n_pad * j.k_pad;
+    const int taps = j.ksize * j.ksize;
+    for (size_t idx = (size_t)bx * 256 + threadIdx.x; idx < total; idx += (size_t)nb * 256) {
+        const int np = (int)(idx / j.k_pad), k = (int)(idx - (size_t)np * j.k_pad);
         int tap, c;
-        if (korder) {
+        if (j.k_order) {
             const int kt = k / bk, cb = kt / taps;
             tap = kt - cb * taps;
             c = cb * bk + (k - kt * bk);
         } else {
-            tap = k / c_pad;
-            c = k - tap * c_pad;
+            tap = k / j.c_pad;
+            c = k - tap * j.c_pad;
         }
         float v = 0.f;
-        if (transpose) {
+        if (j.transpose) {
             // data-gradient weight: row np = input channel c_off + np, K channel `c` = OUTPUT channel, taps flipped
-            if (np < n_rows && tap < taps && c < n_out)
-                v = src[((size_t)c * c_in + (c_off + np)) * taps + (taps - 1 - tap)];
+            if (np < j.n_rows && tap < taps && c < j.n_out)
+                v = src[((size_t)c * j.c_in + (j.c_off + np)) * taps + (taps - 1 - tap)];
         } else {
-            const int n = orig_col(np, n_out, geglu != 0);
-            if (n < n_out && tap < ksize * ksize && c < c_in)
-                v = src[((size_t)n * c_in + c) * (ksize * ksize) + tap];
+            const int n = orig_col(np, j.n_out, j.geglu != 0);
+            if (n < j.n_out && tap < taps && c < j.c_in)
+                v = src[((size_t)n * j.c_in + c) * taps + tap];
         }
         dst[idx] = from_f32<T>(v);
     }
 }
 
 // ---- fast packers for the block-major 16-bit layout (k_order 1, 64-channel blocks) ----------------------------------------
-// The generic kernel above is one thread per packed element with three index divisions, 2-byte stores, and -- for 3x3 and for
+// The generic body above is one thread per packed element with three index divisions, 2-byte stores, and -- for 3x3 and for
 // the transposed (data-gradient) packs -- source reads 36 bytes to kilobytes apart: re-packing the 926 M trained parameters
 // after every optimizer step took 8.4 ms.  These go through an LDS tile so that both sides are contiguous runs.
 // forward, 1x1 / Linear: a row copy with conversion, 4 columns per thread (GEGLU only permutes rows)
 template <typename T>
-__global__ __launch_bounds__(256) void pack_fwd_k1_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_out, int c_in, int k_pad,
-                                                          int n_pad, int geglu) {
-    const int kq = k_pad / 4;
-    const size_t total = (size_t)n_pad * kq;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+__device__ __forceinline__ void pack_fwd_k1_body(const mvldm_pack_job& j, int bx, int nb) {
+    T* __restrict__ dst = reinterpret_cast<T*>(j.dst);
+    const float* __restrict__ src = j.src;
+    const int kq = j.k_pad / 4;
+    const size_t total = (size_t)j.n_pad * kq;
+    for (size_t idx = (size_t)bx * 256 + threadIdx.x; idx < total; idx += (size_t)nb * 256) {
         const int np = (int)(idx / kq), k = (int)(idx - (size_t)np * kq) * 4;
-        const int n = orig_col(np, n_out, geglu != 0);
+        const int n = orig_col(np, j.n_out, j.geglu != 0);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (n < n_out) {
-            const float* sp = src + (size_t)n * c_in + k;
-            if (k + 3 < c_in && (((size_t)n * c_in + k) & 3) == 0) {
+        if (n < j.n_out) {
+            const float* sp = src + (size_t)n * j.c_in + k;
+            if (k + 3 < j.c_in && (((size_t)n * j.c_in + k) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
                 const f32x4 q = *reinterpret_cast<const f32x4*>(sp);
                 v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (k + e < c_in) v[e] = sp[e];
+                for (int e = 0; e < 4; ++e) if (k + e < j.c_in) v[e] = sp[e];
             }
         }
         T o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
-        *reinterpret_cast<u32x2*>(dst + (size_t)np * k_pad + k) = *reinterpret_cast<const u32x2*>(o);
+        *reinterpret_cast<u32x2*>(dst + (size_t)np * j.k_pad + k) = *reinterpret_cast<const u32x2*>(o);
     }
 }
 // forward, 3x3: 4 output rows x one 64-channel block per workgroup; [c][tap] runs of 576 floats in, [tap][c] runs out
 template <typename T>
-__global__ __launch_bounds__(256) void pack_fwd_k3_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_out, int c_in, int c_pad,
-                                                          int n_pad, int k_pad) {
-    __shared__ float lds[4][577];
-    const int ncb = c_pad / 64;
-    const int cb = blockIdx.x % ncb, np0 = (blockIdx.x / ncb) * 4;
+__device__ __forceinline__ void pack_fwd_k3_body(const mvldm_pack_job& j, int bx, float* lds) {
+    T* __restrict__ dst = reinterpret_cast<T*>(j.dst);
+    const float* __restrict__ src = j.src;
+    const int ncb = j.c_pad / 64;
+    const int cb = bx % ncb, np0 = (bx / ncb) * 4;
     for (int i = threadIdx.x; i < 4 * 576; i += 256) {
         const int r = i / 576, e = i - r * 576;
         const int n = np0 + r, c = cb * 64 + e / 9;
-        lds[r][e] = (n < n_out && c < c_in) ? src[((size_t)n * c_in + cb * 64) * 9 + e] : 0.f;
+        lds[r * 577 + e] = (n < j.n_out && c < j.c_in) ? src[((size_t)n * j.c_in + cb * 64) * 9 + e] : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 4 * 576; i += 256) {
         const int r = i / 576, o = i - r * 576;
         const int tap = o >> 6, cw = o & 63;
-        if (np0 + r < n_pad) dst[(size_t)(np0 + r) * k_pad + cb * 576 + o] = from_f32<T>(lds[r][cw * 9 + tap]);
+        if (np0 + r < j.n_pad) dst[(size_t)(np0 + r) * j.k_pad + cb * 576 + o] = from_f32<T>(lds[r * 577 + cw * 9 + tap]);
     }
 }
 // transposed (data-gradient) pack: rows = input channels, K = (64-output-channel block, flipped tap, output channel)
 template <typename T, int KS>
-__global__ __launch_bounds__(256) void pack_t_kernel(const float* __restrict__ src, T* __restrict__ dst, int n_out, int c_in, int c_pad, int n_pad,
-                                                     int k_pad, int c_off, int n_rows) {
+__device__ __forceinline__ void pack_t_body(const mvldm_pack_job& j, int bx, float* lds) {
     constexpr int TAPS = KS * KS, RB = KS == 3 ? 8 : 64, RUN = RB * TAPS, PITCH = RUN + 1;
-    __shared__ float lds[64 * PITCH];
-    const int nnb = c_pad / 64;
-    const int nb = blockIdx.x % nnb, r0 = (blockIdx.x / nnb) * RB;
+    T* __restrict__ dst = reinterpret_cast<T*>(j.dst);
+    const float* __restrict__ src = j.src;
+    const int nnb = j.c_pad / 64;
+    const int nb = bx % nnb, r0 = (bx / nnb) * RB;
     for (int i = threadIdx.x; i < 64 * RUN; i += 256) {
         const int nw = i / RUN, e = i - nw * RUN;
         const int n = nb * 64 + nw, r = r0 + e / TAPS;
-        lds[nw * PITCH + e] = (n < n_out && r < n_rows) ? src[((size_t)n * c_in + c_off + r0) * TAPS + e] : 0.f;
+        lds[nw * PITCH + e] = (n < j.n_out && r < j.n_rows) ? src[((size_t)n * j.c_in + j.c_off + r0) * TAPS + e] : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * RUN; i += 256) {
         const int nw = i & 63, q = i >> 6;
         const int rl = q / TAPS, tp = q - rl * TAPS;
-        if (r0 + rl < n_pad) dst[(size_t)(r0 + rl) * k_pad + (nb * TAPS + tp) * 64 + nw] = from_f32<T>(lds[nw * PITCH + rl * TAPS + (TAPS - 1 - tp)]);
+        if (r0 + rl < j.n_pad) dst[(size_t)(r0 + rl) * j.k_pad + (nb * TAPS + tp) * 64 + nw] = from_f32<T>(lds[nw * PITCH + rl * TAPS + (TAPS - 1 - tp)]);
     }
+}
+
+constexpr int kPackLds = 64 * 73;      // floats: the transposed 3x3 tile (64 output channels x (8 rows x 9 taps + 1))
+template <typename T>
+__global__ __launch_bounds__(256) void pack_job_kernel(const mvldm_pack_job* __restrict__ jobs, int n_jobs, const int32_t* __restrict__ block_job,
+                                                       const mvldm_pack_job single) {
+    __shared__ float lds[kPackLds];
+    mvldm_pack_job j = single;
+    int bx = blockIdx.x;
+    if (jobs) {      // batched launch: the caller's workgroup -> job table, or the last job whose first workgroup is <= this one
+        int lo = 0, hi = n_jobs - 1;      // (block0 ascending; everything here is workgroup-uniform: scalar loads)
+        if (block_job) {
+            lo = block_job[bx];
+        } else {
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (jobs[mid].block0 <= bx) lo = mid; else hi = mid - 1;
+            }
+        }
+        j = jobs[lo];
+        bx -= j.block0;
+    }
+    if constexpr (sizeof(T) == 2) {
+        switch (j.kind) {
+            case PACK_FWD_K1: pack_fwd_k1_body<T>(j, bx, j.blocks); return;
+            case PACK_FWD_K3: pack_fwd_k3_body<T>(j, bx, lds); return;
+            case PACK_T_K3: pack_t_body<T, 3>(j, bx, lds); return;
+            case PACK_T_K1: pack_t_body<T, 1>(j, bx, lds); return;
+            default: break;
+        }
+    }
+    pack_generic_body<T>(j, bx, j.blocks);
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -1613,44 +1653,65 @@ extern "C" size_t mvldm_igemm_workspace_bytes(const mvldm_igemm_desc* d) {
     return (size_t)16 * M * d->n_pad * sizeof(float);
 }
 
+static int pack_job_prepare(mvldm_pack_job& j, int dst_dtype) {
+    const int bk = dst_dtype == MVLDM_F32 ? 32 : 64;
+    MVLDM_REQUIRE(dst_dtype == MVLDM_F32 || dst_dtype == MVLDM_BF16 || dst_dtype == MVLDM_F16, "pack_weight: bad dtype %d", dst_dtype);
+    MVLDM_REQUIRE(j.ksize >= 1 && j.n_out > 0 && j.c_in > 0, "pack_weight: bad dims");
+    MVLDM_REQUIRE(j.k_order == 0 || (j.k_order == 1 && j.c_pad % bk == 0), "pack_weight: k_order 1 needs c_pad %% %d == 0", bk);
+    if (j.transpose)
+        MVLDM_REQUIRE(j.src && j.dst && !j.geglu && j.c_pad >= j.n_out && j.c_off >= 0 && j.n_rows > 0 && j.c_off + j.n_rows <= j.c_in &&
+                      j.n_pad >= j.n_rows && j.k_pad >= j.ksize * j.ksize * j.c_pad, "pack_weight (transpose): bad dims");
+    else
+        MVLDM_REQUIRE(j.src && j.dst && j.c_pad >= j.c_in && j.n_pad >= j.n_out && j.k_pad >= j.ksize * j.ksize * j.c_pad, "pack_weight: bad dims");
+    MVLDM_REQUIRE(!j.geglu || j.n_out % 64 == 0, "pack_weight: GEGLU needs n_out %% 64 == 0");
+    const size_t total = (size_t)j.n_pad * j.k_pad;
+    j.kind = PACK_GENERIC;
+    j.blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+    const int taps = j.ksize * j.ksize;
+    // block-major 16-bit layout: the LDS-tiled packers (same bytes out as the generic body)
+    if (dst_dtype != MVLDM_F32 && j.k_order == 1 && j.c_pad % 64 == 0 && j.k_pad == taps * j.c_pad && (j.ksize == 1 || j.ksize == 3)) {
+        if (j.transpose) {
+            const int rb = j.ksize == 3 ? 8 : 64;
+            j.kind = j.ksize == 3 ? PACK_T_K3 : PACK_T_K1;
+            j.blocks = (j.c_pad / 64) * ((j.n_pad + rb - 1) / rb);
+        } else if (j.ksize == 3) {
+            j.kind = PACK_FWD_K3;
+            j.blocks = (j.c_pad / 64) * ((j.n_pad + 3) / 4);
+        } else {
+            const size_t quads = (size_t)j.n_pad * (j.k_pad / 4);
+            j.kind = PACK_FWD_K1;
+            j.blocks = (int)std::min<size_t>((quads + 255) / 256, 65535);
+        }
+    }
+    return MVLDM_OK;
+}
+
+extern "C" int mvldm_pack_job_prepare(mvldm_pack_job* job, int dst_dtype) {
+    MVLDM_REQUIRE(job != nullptr, "pack_job_prepare: null job");
+    return pack_job_prepare(*job, dst_dtype);
+}
+
+extern "C" int mvldm_pack_weight_batch(const mvldm_pack_job* jobs, int n_jobs, const int32_t* block_job, int total_blocks, int dst_dtype,
+                                       mvldm_stream_t stream) {
+    MVLDM_REQUIRE(n_jobs >= 0 && total_blocks >= 0, "pack_weight_batch: negative count");
+    if (n_jobs == 0 || total_blocks == 0) return MVLDM_OK;
+    MVLDM_REQUIRE(jobs != nullptr, "pack_weight_batch: null job list");
+    return dispatch_dtype(dst_dtype, [&](auto t) {
+        using T = decltype(t);
+        hipLaunchKernelGGL(pack_job_kernel<T>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs, block_job, mvldm_pack_job{});
+        return check_launch();
+    });
+}
+
 extern "C" int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksize, int c_pad, int n_pad,
                                  int k_pad, int geglu, int k_order, int dst_dtype, int transpose, int c_off, int n_rows,
                                  mvldm_stream_t stream) {
-    const int bk = dst_dtype == MVLDM_F32 ? 32 : 64;
-    MVLDM_REQUIRE(k_order == 0 || (k_order == 1 && c_pad % bk == 0), "pack_weight: k_order 1 needs c_pad %% %d == 0", bk);
-    if (transpose)
-        MVLDM_REQUIRE(src && dst && !geglu && c_pad >= n_out && c_off >= 0 && n_rows > 0 && c_off + n_rows <= c_in && n_pad >= n_rows &&
-                      k_pad >= ksize * ksize * c_pad, "pack_weight (transpose): bad dims");
-    else
-        MVLDM_REQUIRE(src && dst && c_pad >= c_in && n_pad >= n_out && k_pad >= ksize * ksize * c_pad, "pack_weight: bad dims");
-    MVLDM_REQUIRE(!geglu || n_out % 64 == 0, "pack_weight: GEGLU needs n_out %% 64 == 0");
-    const size_t total = (size_t)n_pad * k_pad;
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+    mvldm_pack_job j{src, dst, n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu, k_order, transpose, c_off, n_rows, 0, 0, 0};
+    const int rc = pack_job_prepare(j, dst_dtype);
+    if (rc) return rc;
     return dispatch_dtype(dst_dtype, [&](auto t) {
         using T = decltype(t);
-        if constexpr (sizeof(T) == 2) {
-            // block-major 16-bit layout: the LDS-tiled packers (same bytes out as the generic kernel below)
-            const int taps = ksize * ksize;
-            if (k_order == 1 && c_pad % 64 == 0 && k_pad == taps * c_pad && (ksize == 1 || ksize == 3)) {
-                hipStream_t st = (hipStream_t)stream;
-                T* d = reinterpret_cast<T*>(dst);
-                if (transpose) {
-                    const int rb = ksize == 3 ? 8 : 64;
-                    const dim3 grid((c_pad / 64) * ((n_pad + rb - 1) / rb));
-                    if (ksize == 3) hipLaunchKernelGGL((pack_t_kernel<T, 3>), grid, dim3(256), 0, st, src, d, n_out, c_in, c_pad, n_pad, k_pad, c_off, n_rows);
-                    else hipLaunchKernelGGL((pack_t_kernel<T, 1>), grid, dim3(256), 0, st, src, d, n_out, c_in, c_pad, n_pad, k_pad, c_off, n_rows);
-                } else if (ksize == 3) {
-                    hipLaunchKernelGGL(pack_fwd_k3_kernel<T>, dim3((c_pad / 64) * ((n_pad + 3) / 4)), dim3(256), 0, st, src, d, n_out, c_in, c_pad, n_pad, k_pad);
-                } else {
-                    const size_t quads = (size_t)n_pad * (k_pad / 4);
-                    hipLaunchKernelGGL(pack_fwd_k1_kernel<T>, dim3((unsigned)std::min<size_t>((quads + 255) / 256, 65535)), dim3(256), 0, st, src, d, n_out, c_in,
-                                       k_pad, n_pad, geglu);
-                }
-                return check_launch();
-            }
-        }
-        hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
-                           reinterpret_cast<T*>(dst), n_out, c_in, ksize, c_pad, n_pad, k_pad, geglu, k_order, bk, transpose, c_off, n_rows);
+        hipLaunchKernelGGL(pack_job_kernel<T>, dim3((unsigned)j.blocks), dim3(256), 0, (hipStream_t)stream, (const mvldm_pack_job*)nullptr, 0, (const int32_t*)nullptr, j);
         return check_launch();
     });
 }

@@ -282,13 +282,16 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ avg, const
 
 // 16-byte form of the same update: four parameters per thread and memory instruction (7 streams x 3.7 GB per step: the scalar
 // kernel moved them at 4.2 TB/s)
+template <bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel4(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v,
                                                      size_t n4, float lr, float b1, float b2, float eps, float wd, float step_size, float inv_sqrt_bc2,
                                                      float gscale, const float* __restrict__ clip) {
     const float gs = gscale * (clip ? clip[1] : 1.0f);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 g4 = g[i], m4 = m[i], v4 = v[i];
-        f32x4 p4 = p[i], mo, vo;
+        // streamed once per step, 26 GB in all: nothing here is worth a cache line (MVLDM_ADAMW_NT=0: plain loads / stores, A/B)
+        const f32x4 g4 = NT ? __builtin_nontemporal_load(g + i) : g[i], m4 = NT ? __builtin_nontemporal_load(m + i) : m[i],
+                    v4 = NT ? __builtin_nontemporal_load(v + i) : v[i];
+        f32x4 p4 = NT ? __builtin_nontemporal_load(p + i) : p[i], mo, vo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gi = g4[e] * gs;
@@ -300,9 +303,15 @@ __global__ __launch_bounds__(256) void adamw_kernel4(f32x4* __restrict__ p, cons
             pi -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
             p4[e] = pi;
         }
-        m[i] = mo;
-        v[i] = vo;
-        p[i] = p4;
+        if (NT) {
+            __builtin_nontemporal_store(mo, m + i);
+            __builtin_nontemporal_store(vo, v + i);
+            __builtin_nontemporal_store(p4, p + i);
+        } else {
+            m[i] = mo;
+            v[i] = vo;
+            p[i] = p4;
+        }
     }
 }
 
@@ -448,8 +457,13 @@ int adamw_run(float* p, const float* g, float* m, float* v, size_t n, float lr, 
     MVLDM_REQUIRE(p && g && m && v && step >= 1, "adamw: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const bool vec = n % 4 == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
-    if (vec)
-        hipLaunchKernelGGL(adamw_kernel4, dim3(grid_for(n / 4, 2048)), dim3(256), 0, s, reinterpret_cast<f32x4*>(p), reinterpret_cast<const f32x4*>(g),
+    static const bool nt = !(getenv("MVLDM_ADAMW_NT") && atoi(getenv("MVLDM_ADAMW_NT")) == 0);
+    if (vec && nt)
+        hipLaunchKernelGGL(adamw_kernel4<true>, dim3(grid_for(n / 4, 2048)), dim3(256), 0, s, reinterpret_cast<f32x4*>(p), reinterpret_cast<const f32x4*>(g),
+                           reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), n / 4, lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1),
+                           (float)(1.0 / sqrt(bc2)), grad_scale, clip);
+    else if (vec)
+        hipLaunchKernelGGL(adamw_kernel4<false>, dim3(grid_for(n / 4, 2048)), dim3(256), 0, s, reinterpret_cast<f32x4*>(p), reinterpret_cast<const f32x4*>(g),
                            reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), n / 4, lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1),
                            (float)(1.0 / sqrt(bc2)), grad_scale, clip);
     else

@@ -8,8 +8,9 @@ activation dtype; biases / norm parameters / statistics are fp32.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Sequence
 
 import math
 
@@ -111,6 +112,44 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, c_pad: Optional[int] = None
     L.check(L.load().mvldm_pack_weight(w.data_ptr(), out.data_ptr(), n_out, c_in, ksize, c_pad, n_pad, k_pad,
                                        int(geglu), k_order, dt(dtype), 0, 0, n_out, stream()))
     return PackedWeight(out, n_out, n_pad, k_pad, c_pad, ksize, geglu, k_order)
+
+
+def pack_job(w: torch.Tensor, pw: PackedWeight, *, transpose: bool = False, c_off: int = 0) -> "L.PackJob":
+    """the re-pack of `pw` (made by `pack_weight` / `pack_weight_t` from the fp32 weight `w`) as one job of `PackBatch`"""
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    j = L.PackJob()
+    j.src, j.dst = w.data_ptr(), pw.data.data_ptr()
+    j.n_out, j.c_in, j.ksize = w.shape[0], w.shape[1], pw.ksize
+    j.c_pad, j.n_pad, j.k_pad, j.geglu, j.k_order = pw.c_pad, pw.n_pad, pw.k_pad, int(pw.geglu), pw.k_order
+    j.transpose, j.c_off, j.n_rows = int(transpose), c_off, (pw.n_out if transpose else w.shape[0])
+    L.check(L.load().mvldm_pack_job_prepare(C.byref(j), dt(pw.data.dtype)))
+    return j
+
+
+class PackBatch:
+    """many weight re-packs as ONE launch (`mvldm_pack_weight_batch`): the job list lives on the device, a workgroup finds its
+    job by its first-workgroup index.  Same bytes out as one `pack_weight(..., out=)` call per job."""
+
+    def __init__(self, jobs: Sequence["L.PackJob"], dtype: torch.dtype, device):
+        self.n, self.dtype = len(jobs), dtype
+        arr = (L.PackJob * max(len(jobs), 1))()
+        b0 = 0
+        for i, j in enumerate(jobs):
+            C.memmove(C.byref(arr[i]), C.byref(j), C.sizeof(L.PackJob))
+            arr[i].block0 = b0
+            b0 += j.blocks
+        self.total_blocks = b0
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        self.table = raw.to(device)
+        # workgroup -> job (MVLDM_PACK_BLOCK_TABLE=0: the kernel searches the job list instead; A/B)
+        self.block_job = None
+        if os.environ.get("MVLDM_PACK_BLOCK_TABLE", "1") != "0" and jobs:
+            self.block_job = torch.repeat_interleave(torch.arange(len(jobs), dtype=torch.int32), torch.tensor([j.blocks for j in jobs])).to(device)
+            assert self.block_job.numel() == b0
+
+    def run(self):
+        L.check(L.load().mvldm_pack_weight_batch(self.table.data_ptr(), self.n, None if self.block_job is None else self.block_job.data_ptr(),
+                                                 self.total_blocks, dt(self.dtype), stream()))
 
 
 # ------------------------------------------------------------------------------------------ igemm

@@ -563,6 +563,7 @@ class Plan:
 
     def __init__(self, ops, meta, keep, device):
         self.meta, self._keep, self.device = list(meta), list(keep), device
+        self.ops = list(ops)             # the recorded descriptors (host copies: the executor has its own), for inspection
         self.tiles = [int(op.u.igemm.tile) if op.kind == L.OP_IGEMM else None for op in ops]     # 0 = chosen by the library's rules
         arr = (L.Op * max(len(ops), 1))(*ops)
         h = C.c_void_p()

@@ -104,12 +104,13 @@ class TrainBuilder(Builder):
         self.repack: List[Callable[[], None]] = []
         self.touched: set = set()
         self.grad_writes: List[Tuple[int, int, int]] = []      # (op index, flat offset, numel) of every parameter-gradient write
+        self.pack_jobs: List["L.PackJob"] = []                 # one per packed weight (forward and data-gradient packs)
         self._wws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)      # wgrad slabs / colsum / norm partials
+        self.keep.append(self._wws)                            # (the plan outlives this builder: it must own the workspace)
 
     def small_launch(self, rows: int, n_out: int) -> bool:
         """training plans are run in segments between collectives and replay their tape in reverse: no parallel lanes"""
         return False
-        self.keep.append(self._wws)
 
     def free(self, t):      # every activation is kept for the backward pass
         return
@@ -223,13 +224,13 @@ class TrainBuilder(Builder):
             for (c_off, n_rows) in (t_splits or [(0, wsrc.shape[1])]):
                 pts.append((ops.pack_weight_t(wsrc, self.dtype, c_off, n_rows), c_off, n_rows))
 
-        def repack():
-            if refresh is not None:
-                refresh()
-            ops.pack_weight(wsrc, self.dtype, c_pad=c_pad, c_split=c_split, out=pw.data)
-            for pt, c_off, n_rows in pts:
-                ops.pack_weight_t(wsrc, self.dtype, c_off, n_rows, out=pt.data)
-        self.repack.append(repack)
+        # after an optimizer step: the fp32 sources that are copies first (`repack`), then every pack -- one job each of the
+        # plan's single batched launch (`pack_jobs`; TrainPlan.refresh_weights)
+        if refresh is not None:
+            self.repack.append(refresh)
+        self.pack_jobs.append(ops.pack_job(wsrc, pw))
+        for pt, c_off, n_rows in pts:
+            self.pack_jobs.append(ops.pack_job(wsrc, pt, transpose=True, c_off=c_off))
         self.keep.extend([wsrc, pw.data] + [p[0].data for p in pts])
         return pw, [p[0] for p in pts]
 
@@ -747,14 +748,25 @@ class TrainPlan:
         assert not bld.tape
         self.eps, self.unet_in, self.tgt_img = eps, unet_in, tgt_img
         self.touched, self.grad_writes, self.repack = bld.touched, bld.grad_writes, bld.repack
+        self.pack_jobs, self._pack_dtype = bld.pack_jobs, dtype
+        self._pack_batch = ops.PackBatch(bld.pack_jobs, dtype, dev) if os.environ.get("MVLDM_TRAIN_PACK_BATCH", "1") != "0" else None
         self.plan: Plan = bld.finalize(autotune=tune)
         self.graph = graph
         if graph:       # (capturing runs the plan once eagerly: the caller restores the gradient / loss accumulators)
             self.plan.capture()
 
     def refresh_weights(self):
+        """after an optimizer step: bring the packed (forward + data-gradient) weights and the summed / concatenated fp32 copies up
+        to date.  The ~380 packs are ONE launch (`ops.PackBatch`: 7.2 -> ... ms against one launch per pack, which is latency-bound);
+        MVLDM_TRAIN_PACK_BATCH=0 keeps the per-pack launches (A/B; same bytes)."""
         for fn in self.repack:
             fn()
+        if self._pack_batch is not None:
+            self._pack_batch.run()
+        else:
+            for j in self.pack_jobs:
+                L.check(L.load().mvldm_pack_weight(j.src, j.dst, j.n_out, j.c_in, j.ksize, j.c_pad, j.n_pad, j.k_pad, j.geglu, j.k_order,
+                                                   dt(self._pack_dtype), j.transpose, j.c_off, j.n_rows, ops.stream()))
 
     def run(self, first: int = 0, last: Optional[int] = None):
         if self.graph and first == 0 and last is None:

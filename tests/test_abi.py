@@ -39,15 +39,17 @@ def test_struct_layout_matches_header(tmp_path):
     from mv_ldm_amd import _lib
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mvldm.h"\nint main(){'
-                   'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mvldm_igemm_desc), sizeof(mvldm_op),'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mvldm_igemm_desc), sizeof(mvldm_op),'
                    'offsetof(mvldm_op,u), offsetof(mvldm_igemm_desc,c0), offsetof(mvldm_igemm_desc,out_scale),'
-                   'offsetof(mvldm_igemm_desc,workspace_bytes), offsetof(mvldm_op,u.attention.scale));return 0;}')
+                   'offsetof(mvldm_igemm_desc,workspace_bytes), offsetof(mvldm_op,u.attention.scale),'
+                   'sizeof(mvldm_pack_job), offsetof(mvldm_pack_job,n_out), offsetof(mvldm_pack_job,block0));return 0;}')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(_lib.IgemmDesc), C.sizeof(_lib.Op), _lib.Op.u.offset, _lib.IgemmDesc.c0.offset,
             _lib.IgemmDesc.out_scale.offset, _lib.IgemmDesc.workspace_bytes.offset,
-            _lib.Op.u.offset + _lib._Attention.scale.offset]
+            _lib.Op.u.offset + _lib._Attention.scale.offset,
+            C.sizeof(_lib.PackJob), _lib.PackJob.n_out.offset, _lib.PackJob.block0.offset]
     assert got == want
 
 

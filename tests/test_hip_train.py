@@ -151,6 +151,71 @@ def test_accumulation_window_as_one_plan_equals_micro_batch_steps(golden, dtype)
         assert float((w0 - w1).abs().max()) < 2e-5          # one AdamW step of lr 1e-3 from (almost) the same gradients
 
 
+def test_plan_owns_every_workspace_its_ops_point_into(golden):
+    """the recorded training plan outlives the builder that made it: every scratch pointer inside its weight-gradient / column-sum /
+    norm-backward ops must lie in a tensor the plan itself keeps alive (a builder-owned workspace would go back to the caching
+    allocator and be handed to someone else while the plan still writes into it)"""
+    from mv_ldm_amd import _lib as L
+    g = golden("g9_training_step")
+    tr = build_trainer(g, torch.float32)
+    batch, ch = g9_case(g, 0)
+    tr.training_step(batch, **hip_choices(ch))
+    tp = next(iter(tr.plans.values()))
+    spans = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in tp.plan._keep if isinstance(t, torch.Tensor) and t.is_cuda]
+    seen = 0
+    for op in tp.plan.ops:
+        for kind, member in ((L.OP_WGRAD, "wgrad"), (L.OP_COLSUM, "colsum"), (L.OP_GROUPNORM_BWD, "groupnorm_bwd"), (L.OP_LAYERNORM_BWD, "layernorm_bwd")):
+            if op.kind == kind:
+                u = getattr(op.u, member)
+                if u.workspace and u.workspace_bytes:
+                    seen += 1
+                    assert any(a <= u.workspace and u.workspace + u.workspace_bytes <= b for a, b in spans), f"{member}: workspace not owned by the plan"
+    assert seen > 10
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_batched_repack_writes_the_bytes_of_the_per_pack_launches(golden, dtype, monkeypatch):
+    """`mvldm_pack_weight_batch` (one launch for every forward / data-gradient pack of the plan, TrainPlan.refresh_weights) against
+    one `mvldm_pack_weight` launch per pack: the same bytes in every packed buffer after the weights have moved"""
+    g = golden("g9_training_step")
+    tr = build_trainer(g, dtype)
+    batch, ch = g9_case(g, 0)
+    tr.training_step(batch, **hip_choices(ch))
+    tp = next(iter(tr.plans.values()))
+    assert tp._pack_batch is not None and tp._pack_batch.n == len(tp.pack_jobs) > 20
+    kinds = {j.kind for j in tp.pack_jobs}
+    assert (kinds >= {1, 2, 3, 4}) if dtype == torch.bfloat16 else (kinds == {0}), kinds      # every packer body is exercised
+    es = 2 if dtype == torch.bfloat16 else 4
+    with torch.no_grad():
+        tr.flat.flat.add_(torch.randn_like(tr.flat.flat) * 0.05)
+    # the packed tensors are the `dst` of the jobs: find them among the tensors the plan keeps
+    by_ptr = {t.data_ptr(): t for t in tp.plan._keep if isinstance(t, torch.Tensor) and t.is_cuda}
+    dsts = [by_ptr[j.dst] for j in tp.pack_jobs]
+    for d in dsts:
+        d.view(torch.uint8).fill_(0xAB)
+    assert tp._pack_batch.block_job is not None
+    tp.refresh_weights()
+    torch.cuda.synchronize()
+    batched = [d.view(torch.uint8).clone() for d in dsts]
+    for d in dsts:
+        d.view(torch.uint8).fill_(0x5A)
+    table, tp._pack_batch.block_job = tp._pack_batch.block_job, None       # the same launch finding its jobs by binary search
+    tp.refresh_weights()
+    torch.cuda.synchronize()
+    tp._pack_batch.block_job = table
+    for j, a, d in zip(tp.pack_jobs, batched, dsts):
+        assert torch.equal(a, d.view(torch.uint8)), f"pack kind {j.kind}: job search and job table differ"
+    for d in dsts:
+        d.view(torch.uint8).fill_(0xCD)
+    saved, tp._pack_batch = tp._pack_batch, None
+    tp.refresh_weights()
+    torch.cuda.synchronize()
+    tp._pack_batch = saved
+    for j, a, d in zip(tp.pack_jobs, batched, dsts):
+        assert torch.equal(a, d.view(torch.uint8)), f"pack kind {j.kind} ({j.n_out}x{j.c_in}, k {j.ksize}, transpose {j.transpose}) differs"
+        assert not bool((a == 0xAB).all())
+
+
 def test_inference_plans_follow_in_place_optimizer_steps(golden):
     """the fused AdamW kernel updates the flat fp32 parameters in place, invisible to torch's version counters: recorded
     INFERENCE plans (raw pointers to PACKED weight copies) must be re-recorded after it (modules.bump_weights_epoch)"""

@@ -32,6 +32,39 @@ def timed(f):
     torch.cuda.synchronize(); t = time.perf_counter(); r = f(); torch.cuda.synchronize(); return r, 1e3 * (time.perf_counter() - t)
 
 acc = {}
+def add(k, t):
+    acc[k] = acc.get(k, 0) + t
+
+N = 4
+window = [batch, batch]
+if os.environ.get("MVLDM_TIMELINE_PER_MICRO") != "1":
+    # the accumulation window as ONE plan (MVLDMTrainer.training_window), phase by phase with a device sync between phases
+    for _ in range(2):
+        tr.training_window(window, [dict(index=1, unconditional=False)] * 2)
+    torch.cuda.synchronize()
+    t_all = time.perf_counter()
+    for _ in range(N):
+        tr.training_window(window, [dict(index=1, unconditional=False)] * 2)
+    torch.cuda.synchronize()
+    whole = 1e3 * (time.perf_counter() - t_all) / N
+    for it in range(N):
+        parts, t = timed(lambda: [tr._host_part(bt, index=1, unconditional=False) for bt in window]); add("host part (image upload, cameras)", t)
+        lats, t = timed(lambda: tr._encode([p_["x"] for p_ in parts], [p_["encode_noise"] for p_ in parts])); add("VAE encode (one call, 32 views)", t)
+        parts, t = timed(lambda: [tr._finish_part(p_, lat) for p_, lat in zip(parts, lats)]); add("draws (noise, timesteps)", t)
+        _, t = timed(lambda: (tr.flat.zero_grad(), [p.loss.zero_() for p in tr.plans.values()])); add("zero_grad", t)
+        hl, wl = parts[0]["lat"].shape[-2:]
+        tp = tr.plan_for_parts([(p_["b"], p_["vc_eff"], p_["v_t"]) for p_ in parts], hl, wl)
+        _, t = timed(lambda: [tr._stage_part(tp, i, p_) for i, p_ in enumerate(parts)]); add("stage inputs into the plan's buffers", t)
+        _, t = timed(lambda: tr._fresh(tp)); add("wait for / do the weight re-pack", t)
+        _, t = timed(tp.run); add("plan (fwd + loss + bwd, 2 micro-batches)", t)
+        tr.micro += 2
+        _, t = timed(tr.opt.step); add("optimizer step (norm, clip, AdamW)", t)
+        tr.global_step += 1
+        tr._weights_gen += 1
+        _, t = timed(lambda: tr._repack_ahead(tp)); add("weight re-pack (side stream, here waited for)", t)
+    print({k: round(v / N, 2) for k, v in acc.items()}, "ms per optimizer step, phases serialised;", round(sum(acc.values()) / N, 2), "ms summed;",
+          round(whole, 2), "ms per training_window() unserialised")
+    sys.exit(0)
 for it in range(3):
     for micro in range(2):
         if micro == 0:
