@@ -140,6 +140,10 @@ int mvldm_pack_weight_batch(const mvldm_pack_job* jobs /* device */, int n_jobs,
 int mvldm_groupnorm_fwd(const void* x0, const void* x1, void* y, const float* gamma, const float* beta, int n_img,
                         int hw, int c0, int c1, int groups, float eps, int silu, int dtype, void* stats_ws,
                         float* stats_out, mvldm_stream_t stream);
+/* how many times that call moves the tensor over HBM: 2 (one launch, the (image, channel-span) slab stays in registers:
+ * 1 read + 1 write) or 3 (statistics launch + apply launch: 2 reads + 1 write).  Host-side query (no GPU work) for the
+ * byte accounting of plans and benches. */
+int mvldm_groupnorm_passes(int n_img, int hw, int c, int groups, int dtype);
 
 /* LayerNorm over the last dim of [rows][c].  replaces torch.nn.LayerNorm in BasicTransformerBlock
  * (diffusers) and BasicTransformerBlock3D norm1-3 (mvdream/attention.py:286-288,363-367). */

@@ -189,6 +189,7 @@ SIGNATURES = {
     "mvldm_pack_job_prepare": (C.c_int, [C.POINTER(PackJob), C.c_int]),
     "mvldm_pack_weight_batch": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp, vp]),
+    "mvldm_groupnorm_passes": (C.c_int, [C.c_int] * 5),
     "mvldm_layernorm_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, C.c_int, vp]),
     "mvldm_attention_fwd": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp, C.c_int, C.c_int, f32, C.c_int, vp, C.c_int, vp]),
     "mvldm_igemm_wgrad": (C.c_int, [C.POINTER(WgradDesc), vp]),

@@ -484,6 +484,13 @@ int layernorm_run(const void* x, void* y, const float* gamma, const float* beta,
 
 }  // namespace mvldm
 
+extern "C" int mvldm_groupnorm_passes(int n_img, int hw, int c, int groups, int dtype) {
+    if (n_img <= 0 || hw <= 0 || groups <= 0 || c <= 0 || c % groups) return 3;
+    static const int no_fused = getenv("MVLDM_GN_TWOPASS") ? atoi(getenv("MVLDM_GN_TWOPASS")) : 0;
+    int nthr = 0, kt = 0;
+    return (!no_fused && mvldm::gn_fused_plan(hw, c, groups, dtype == MVLDM_F32 ? 4 : 8, n_img, nthr, kt)) ? 2 : 3;
+}
+
 extern "C" int mvldm_groupnorm_fwd(const void* x0, const void* x1, void* y, const float* gamma, const float* beta,
                                    int n_img, int hw, int c0, int c1, int groups, float eps, int silu, int dtype,
                                    void* stats_ws, float* stats_out, mvldm_stream_t stream) {

@@ -283,7 +283,9 @@ class Builder:
         g.stats_ws = self.gn_ws(n, groups).data_ptr()
         g.n_img, g.hw, g.c0, g.c1, g.groups, g.silu, g.dtype, g.eps = n, hw, c0, c1, groups, int(silu), dt(x), eps
         g.stats_out = ptr(stats_out)
-        self._emit(op, name, 0.0, 3.0 * y.numel() * y.element_size(), (x, x2, y, gamma, beta, stats_out))
+        # bytes: what the chosen kernel form moves (fused: 1 read + 1 write; statistics + apply launches: 2 reads + 1 write)
+        passes = L.load().mvldm_groupnorm_passes(n, hw, c0 + c1, groups, dt(x))
+        self._emit(op, name, 0.0, float(passes) * y.numel() * y.element_size(), (x, x2, y, gamma, beta, stats_out))
         return y
 
     def layernorm(self, x, gamma, beta, eps=1e-5, name="layernorm"):

@@ -11,7 +11,7 @@ for name, h, c0, c1 in (("L0.320", 32, 320, 0), ("L0.640+320", 32, 640, 320), ("
     x = torch.randn(n, h, h, c0, device="cuda").to(torch.bfloat16)
     x2 = torch.randn(n, h, h, c1, device="cuda").to(torch.bfloat16) if c1 else None
     g, b = torch.randn(c0 + c1, device="cuda"), torch.randn(c0 + c1, device="cuda")
-    f = lambda: ops.groupnorm(x, g, b, 32, 1e-5, True, x2=x2)
+    f = lambda: ops.groupnorm(x, g, b, 32, 1e-5, os.environ.get("GN_SILU", "1") != "0", x2=x2)
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
