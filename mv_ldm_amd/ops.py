@@ -183,8 +183,9 @@ def igemm_desc(src0, src1, pw: PackedWeight, dst, *, n_img, h_in, w_in, h_out, w
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, bias=None, *, x2=None, stride=1, pad=None, upsample=False, row_bias=None,
-           residual=None, epilogue=L.EPI_NONE, out_dtype=None, out_scale=1.0, splitk=0, tile=0) -> torch.Tensor:
-    """x: NHWC `[n, h, w, c]`; x2: optional second source concatenated along c.  Returns NHWC."""
+           residual=None, epilogue=L.EPI_NONE, out_dtype=None, out_scale=1.0, splitk=0, tile=0, out=None) -> torch.Tensor:
+    """x: NHWC `[n, h, w, c]`; x2: optional second source concatenated along c.  Returns NHWC.  `out`: write into this tensor
+    (it may be the residual: x += f(x))."""
     assert x.is_cuda and x.is_contiguous() and (x2 is None or x2.is_contiguous())
     n, h, w, _ = x.shape
     pad = (pw.ksize // 2) if pad is None else pad
@@ -194,7 +195,11 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, bias=None, *, x2=None, stride=1, p
     else:
         ho, wo = (hs + 2 * pad - pw.ksize) // stride + 1, (ws_ + 2 * pad - pw.ksize) // stride + 1
     n_dst = pw.n_out // 2 if epilogue == L.EPI_GEGLU else pw.n_out
-    out = torch.empty(n, ho, wo, n_dst, dtype=out_dtype or x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty(n, ho, wo, n_dst, dtype=out_dtype or x.dtype, device=x.device)
+    else:
+        assert out.is_contiguous() and out.numel() == n * ho * wo * n_dst and out.dtype == (out_dtype or x.dtype)
+        out = out.view(n, ho, wo, n_dst)
     scratch = None
     if splitk != 1:
         # split-K only pays when M*N is small: the C side lowers the split count to what fits
@@ -239,11 +244,11 @@ def conv2d_upsample_phases(x: torch.Tensor, pws, bias=None, tile=0, splitk=0) ->
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, bias=None, *, residual=None, epilogue=L.EPI_NONE, out_dtype=None,
-           splitk=0, tile=0) -> torch.Tensor:
+           splitk=0, tile=0, out=None) -> torch.Tensor:
     """x: `[rows, c]` token matrix."""
     rows, c = x.shape
     y = conv2d(x.view(rows, 1, 1, c), pw, bias, residual=None if residual is None else residual.view(rows, 1, 1, -1),
-               epilogue=epilogue, out_dtype=out_dtype, splitk=splitk, tile=tile)
+               epilogue=epilogue, out_dtype=out_dtype, splitk=splitk, tile=tile, out=out)
     return y.view(rows, -1)
 
 

@@ -455,7 +455,7 @@ class Builder:
 # Results are cached per problem signature for the life of the process.  MVLDM_AUTOTUNE=0 keeps the rules;
 # MVLDM_TUNE_TILES=0,2,9,... restricts the candidates (the small 64x64 / 32x64 tiles only ever win below ~4 scenes: +2 % at b = 1).
 _TUNE_CACHE = {}
-_TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) if os.environ.get("MVLDM_TUNE_TILES") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)
+_TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) if os.environ.get("MVLDM_TUNE_TILES") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)
 
 
 def _igemm_signature(d) -> tuple:

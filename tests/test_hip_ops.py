@@ -237,6 +237,92 @@ def test_persistent_tile_two_sources(ops, dtype, n, h, c0, c1, cout):
     assert (y.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,cin,cout", [(300, 320, 320), (1000, 384, 960), (2500, 640, 200), (70000, 320, 64), (20000, 1280, 328),
+                                           (66000, 320, 640), (40001, 640, 1280)])
+def test_linear_wide_persistent_tile(ops, dtype, rows, cin, cout):
+    """tile 13 (linear_pw.hip: persistent 256 x 320 / 256 x 256 tiles, 4-slot BK = 32 ring across tile boundaries, epilogue straight
+    from the accumulators through the permuted-column transposed product): ragged M / N, N a multiple of 320 (5 column blocks per
+    wave) and not (4), more tiles than workgroups, residual (rolling asm loads) and none, no bias"""
+    x, wt = rnd((rows, cin), 41, dtype), rnd((cout, cin), 42, dtype, 1 / math.sqrt(cin))
+    b = torch.randn(cout, generator=G(43)) * 0.1
+    res = rnd((rows, cout), 44, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    lin = F.linear(x.double(), wt.double(), b.double())
+    xg = x.to(dtype).cuda()
+    y = ops.linear(xg, pw, b.cuda(), residual=res.to(dtype).cuda(), tile=13)
+    close(y.float().cpu().double(), lin + res.double(), dtype, "linear+res tile13")
+    y = ops.linear(xg, pw, None, tile=13)
+    close(y.float().cpu().double(), F.linear(x.double(), wt.double()), dtype, "linear nobias tile13")
+    y = ops.linear(xg, pw, b.cuda(), tile=13)
+    close(y.float().cpu().double(), lin, dtype, "linear tile13")
+    y0 = ops.linear(xg, pw, b.cuda(), tile=7)       # same MFMA K order; the bias enters first here, last there
+    assert (y.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
+    assert (y != y0).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,c", [(300, 320), (33000, 320), (5000, 640)])
+def test_geglu_wide_persistent_tile(ops, dtype, rows, c):
+    """tile 13 with the GEGLU pairing: value and gate of a column sit in the same lane (same row permutation for both blocks)"""
+    x, wt = rnd((rows, c), 45, dtype), rnd((8 * c, c), 46, dtype, 1 / math.sqrt(c))
+    b = torch.randn(8 * c, generator=G(47)) * 0.1
+    pw = ops.pack_weight(wt.cuda(), dtype, geglu=True)
+    a, g = F.linear(x.double(), wt.double(), b.double()).chunk(2, -1)
+    y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=13)
+    assert y.shape == (rows, 4 * c)
+    close(y.float().cpu().double(), a * F.gelu(g), dtype, "geglu tile13")
+    y7 = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=7)
+    assert (y.float() - y7.float()).abs().max().item() <= 2e-2 * y7.float().abs().max().item()
+    assert (y != y7).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,h,c0,c1,cout", [(3, 16, 320, 320, 320), (5, 8, 640, 320, 640), (2, 32, 64, 576, 200)])
+def test_wide_persistent_tile_two_sources(ops, dtype, n, h, c0, c1, cout):
+    """tile 13 on the 1x1 shortcut conv of an up-block resnet (never-materialised channel concat): K-steps [0, c0/32) stream from the
+    first tensor, the rest from the second"""
+    x, x2 = rnd((n, c0, h, h), 51, dtype), rnd((n, c1, h, h), 52, dtype)
+    w = rnd((cout, c0 + c1), 53, dtype, 1 / math.sqrt(c0 + c1))
+    b = torch.randn(cout, generator=G(54)) * 0.1
+    pw = ops.pack_weight(w.cuda(), dtype, c_split=c0)
+    ref = F.conv2d(torch.cat([x, x2], 1).double(), w.double()[:, :, None, None], b.double())
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=nhwc(x2, dtype), tile=13)
+    close(nchw(y), ref, dtype, "dual-source 1x1 tile13")
+
+
+def test_wide_persistent_tile_race_screen(ops):
+    """like the tile-12 screen: the counted-vmcnt ring across tile boundaries, the rolling asm residual loads and the asm stores of
+    tile 13 must give bit-identical results launch after launch while another stream keeps the memory system busy"""
+    torch.manual_seed(0)
+    side, noise = torch.cuda.Stream(), torch.randn(16 << 20, device="cuda")
+    for rows, k, n, epi, res in ((150000, 320, 2560, 2, False), (70001, 384, 200, 0, True), (200000, 320, 320, 0, True), (90000, 640, 1920, 0, False)):
+        x = torch.randn(rows, k, device="cuda").to(torch.bfloat16)
+        pw = ops.pack_weight(torch.randn(n, k, device="cuda") / k ** 0.5, torch.bfloat16, geglu=epi == 2)
+        b = torch.randn(n, device="cuda")
+        r = torch.randn(rows, n, device="cuda").to(torch.bfloat16) if res else None
+        ref = ops.linear(x, pw, b, residual=r, epilogue=epi, tile=13).clone()
+        ref7 = ops.linear(x, pw, b, residual=r, epilogue=epi, tile=7)
+        assert (ref.float() - ref7.float()).abs().max().item() <= 2e-2 * ref7.float().abs().max().item()
+        for i in range(40):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    noise.mul_(1.0001)
+            assert torch.equal(ops.linear(x, pw, b, residual=r, epilogue=epi, tile=13), ref), (rows, i)
+    torch.cuda.synchronize()
+
+
+def test_wide_persistent_tile_in_place_residual(ops):
+    """x += f(x): the residual aliases the destination (every transformer sub-block of the UNet runs this way)"""
+    dtype = torch.bfloat16
+    x, wt = rnd((30000, 320), 61, dtype), rnd((320, 320), 62, dtype, 1 / math.sqrt(320))
+    h = rnd((30000, 320), 63, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    hg = h.to(dtype).cuda()
+    y = ops.linear(x.to(dtype).cuda(), pw, None, residual=hg, out=hg, tile=13)
+    close(y.float().cpu().double(), F.linear(x.double(), wt.double()) + h.double(), dtype, "in-place residual tile13")
+
+
 def test_persistent_tile_race_screen(ops):
     """the counted-vmcnt ring, the prefetch across tile boundaries and the asm stores of tile 12 are the kind of code whose
     hazards show up as RARE wrong tiles: the same launch, repeated while another stream keeps the memory system busy, must be
