@@ -5,24 +5,30 @@
 // one-tile-per-workgroup kernels (igemm.hip) ring fill, main loop and epilogue of a tile ADD UP on a CU that holds one workgroup;
 // the LDS park of the epilogue alone (160 ds_write_b32 + 80 ds_read_b128 per wave and tile) is as long as the main loop at
 // K = 320.  Tile 12 (linear_pp.hip) hides the epilogue under the next tile's MFMAs but pays for its two accumulator sets with a
-// 128-column tile: 85 flop per L2->LDS byte, and these shapes are bound by that fill.  This kernel keeps the WIDE tile
-// (256 x 320, or 256 x 256 for GEGLU: 142 / 128 flop per byte) and removes the other two costs:
-//   * PERSISTENT: a workgroup walks its output tiles as one stream of K-steps of 32 (BK = 32: 36 KB per step at 256 x 320); the
-//     4-slot LDS-DMA ring never drains -- step g+3 is issued at the top of step g, across tile boundaries, so three steps
-//     (110 KB) are in flight per CU at any time and the next tile's first three steps land while the epilogue runs;
+// 128-column tile: 85 flop per L2->LDS byte.  This kernel keeps the WIDE tile (256 x 320, or 256 x 256 for GEGLU: 142 / 128 flop
+// per byte) and removes the other two costs:
+//   * PERSISTENT: a workgroup walks its output tiles as one stream of K-steps of 64; the 2-slot LDS-DMA ring (2 x 72 KB at 256 x 320)
+//     never drains -- a slot is retired as soon as its last fragments are in registers (in front of the step's last quarter) and
+//     refilled at once with step g+2, across tile boundaries, so the next tile's first two steps land while the epilogue runs;
 //   * PARK-FREE EPILOGUE: the product is computed transposed (W fragment = MFMA A operand), so a lane holds ONE output row; the
 //     W rows a wave feeds to the MFMA's M index are PERMUTED (mu = 8a + 4h + e  <-  column 16(a>>1) + 8h + 4(a&1) + e of the
 //     32-column block), which costs nothing (it is the lane's LDS read address) and leaves accumulator registers 0..7 / 8..15 of
 //     a lane = 8 + 8 CONSECUTIVE output columns: two 16-byte stores per 32 x 32 block straight from registers -- no LDS park, no
 //     v_permlane swaps; a store instruction covers 32 rows x 32 contiguous bytes.  GEGLU: value and gate blocks use the same
 //     permutation, so a lane holds a column's value AND gate.
-// Counted waits: every wave issues the same VMEM sequence.  All loads (bias slab, residual) are hipcc-visible builtins consumed
-// behind explicit waits; the output stores are inline asm (hipcc treats loads and stores in flight as unordered and would fall back
-// to vmcnt(0) around them) and are issued at the END of the epilogue, after the last load has been consumed, so the compiler's
-// model and the hardware counter agree wherever a load is waited for.  Steps 0..2 of a tile need no wait (the epilogue's load
-// wait retired every older ring piece: VMEM returns in order); from step 3 on vmcnt(2P) leaves two steps in flight.
-// LDS rows are 64 bytes (4 x 16-byte chunks), chunk index XOR (row >> 2) & 3: the 16-lane groups of a ds_read_b128 fragment read
-// hit 16 distinct 16-byte slots (checked for the natural AND the permuted row order, which keeps the lane groups' row sets).
+// Counted waits: every wave issues the same VMEM sequence.  The loads of the epilogue (bias slab; residual: inline asm, rolling
+// window) are consumed behind explicit waits; the output stores are inline asm (hipcc treats loads and stores in flight as unordered
+// and would fall back to vmcnt(0) around them) and are issued at the END of the epilogue, after the last load has been consumed.
+// VMEM returns in order: the wait in a tile's step 0 (for step 1's pieces, issued by the previous tile's last step) leaves exactly the
+// previous epilogue's stores outstanding; the first wait that has to count them is the one in step 1.  The epilogue itself does not
+// drain the ring: the next tile's bias is requested before the last step's pieces and waited for with those in flight.
+// History of the round (profiles/r04_pw_probe_*.txt, r04_dma_rate_probe.txt): the first version used K-steps of 32 in a 4-slot
+// ring (64-byte LDS rows).  tools/pw_probe.py showed its K loop sound (L0 QKV at 64 scenes 371 us with the stores off, 664 with)
+// but tools/probe/dma_rate.hip showed what 64-byte row pieces cost: an LDS-DMA stream of half cache lines runs at 16 TB/s from a hot
+// L2 against 28 TB/s with full 128-byte lines, and at 3.6 against 6.2 TB/s from HBM (every line fetched twice).  Hence full lines
+// (BK = 64, the XOR-swizzled 128-byte LDS rows of igemm.hip) and the deepest ring 160 KB allow.  Write-back (not streaming) stores:
+// the L2 acknowledges a tile's store burst (160 KB per CU, every CU at once) long before HBM has taken it, which is what the next
+// tile's first counted wait needs (QKV 712 -> 552 us).
 #include <algorithm>
 #include <cstdlib>
 
@@ -34,17 +40,21 @@ struct LinPWParams {
     const void* a; const void* a1; const void* w; const float* bias; const void* residual; void* dst;
     int M, K, c0, c1, kt0, n_out, n_pad, n_dst, dst_ld, k_steps;    // K = c0 + c1; K-steps [0, kt0) come from `a`, the rest from `a1`
     int tiles_m, tiles_n, m_per;       // m_per: 256-row blocks per XCD
-    int cpt, nch;                      // a unit = up to `cpt` consecutive column tiles of one row block; nch units per row block
+    int gm, gn, nbn;                   // an XCD's workgroups cover gm x gn blocks of tiles, column chunks (nbn of them) fastest
     int nt_store;
     float out_scale;
     unsigned a_bytes, a1_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
 };
 
-static const int kPwCpt = getenv("MVLDM_PW_CPT") ? atoi(getenv("MVLDM_PW_CPT")) : 0;   // tuning: force the unit length
 #ifdef MVLDM_EXPERIMENTS
 static const int kPwFake = getenv("MVLDM_PW_FAKE") ? atoi(getenv("MVLDM_PW_FAKE")) : 0;   // 1: no A traffic, 2: no W traffic, 4: no stores
 #else
 static constexpr int kPwFake = 0;
+#endif
+#ifdef MVLDM_EXPERIMENTS_NOGELU
+#define PW_GELU(x) (x)
+#else
+#define PW_GELU(x) gelu_erf_fast(x)
 #endif
 
 constexpr unsigned kPwOob = 0xFFFFFFF0u;
@@ -53,13 +63,12 @@ constexpr int PW_BM = 256, PW_NW = 8;
 
 template <int TN> struct PwGeo {
     static constexpr int BN = 64 * TN;                  // 2 column waves of TN 32-column blocks
-    static constexpr int A_SLOT = PW_BM * 64, W_SLOT = BN * 64, STAGE = A_SLOT + W_SLOT;
-    static constexpr int W_PIECES = BN / 16;            // 1 KiB DMA pieces (16 rows of 64 bytes) of a W step
-    static constexpr int W_IT = (W_PIECES + PW_NW - 1) / PW_NW;
-    static constexpr int P = 2 + W_IT;                  // DMA instructions per wave and step (A: 2)
-    static constexpr int RING = 4 * STAGE;
-    static constexpr int DUMMY = RING;                  // target of the padding pieces (TN = 5: waves 4..7 issue a third W piece nobody reads)
-    static constexpr int SLAB = RING + 1024;            // bias of the tile's BN packed columns
+    static constexpr int A_SLOT = PW_BM * 128, W_SLOT = BN * 128, STAGE = A_SLOT + W_SLOT;
+    static constexpr int A_IT = PW_BM / 8 / PW_NW;      // 1 KiB DMA pieces (8 rows of 128 bytes) per wave: activation rows
+    static constexpr int W_IT = BN / 8 / PW_NW;         // ... weight rows (= TN)
+    static constexpr int P = A_IT + W_IT;               // DMA instructions per wave and step
+    static constexpr int RING = 2 * STAGE;
+    static constexpr int SLAB = RING;                   // bias of the tile's BN packed columns
     static constexpr int SMEM = SLAB + 2048;
 };
 
@@ -75,61 +84,87 @@ template <> struct PwMma<f16_t> {
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
-// MFMA M index mu (= lane & 31 of the W-fragment read) -> column of the 32-column block it is fed from (header)
+// MFMA M index mu (= lane & 31 of the W-fragment read) -> column of the 32-column block it is fed from (header).  The permutation
+// maps each 16-lane group of a ds_read_b128 onto the same SET of rows as the identity, so the swizzle stays conflict-free.
 __device__ __forceinline__ int pw_perm(int mu) {
     const int a = mu >> 3, h = (mu >> 2) & 1, e = mu & 3;
     return 16 * (a >> 1) + 8 * h + 4 * (a & 1) + e;
 }
 
+// Source addressing of a wave's DMA pieces.  Piece `it` of a wave covers tile rows (wave + 8 it) * 8 .. + 7, a lane fetches the
+// 16-byte chunk that belongs at its (linear) LDS position under the XOR swizzle; (row >> 1) & 7 does not depend on `it`, so ONE
+// per-lane byte offset serves all pieces of an operand and the piece's 64-row stride rides in the scalar offset with the K position.
+struct PwAddr {
+    unsigned a0, a1;     // activation rows of piece 0: byte offset into the first / second source (channel concat)
+    unsigned w;          // weight rows of piece 0
+    int m0, n0;          // first row of the tile this lane's pieces belong to (validity: m0 + row < M; W pieces: wave-uniform)
+    bool valid;
+};
+
 // (buffer descriptors only in free functions: an opaque __amdgpu_buffer_rsrc_t inside a lambda trips hipcc's host pass)
+// The DMA pieces of a step are issued in two groups (activation rows, weight rows) so that the main loop can place each between
+// MFMAs: issued back to back at the top of a step they held BOTH waves of a SIMD in the address path while its matrix pipe idled.
 template <int TN>
-__device__ __forceinline__ void pw_issue(const LinPWParams& p, char* smem, int slot, int wave, int ks, const unsigned (&ao)[2][2],
-                                         const unsigned (&bo)[3]) {
+__device__ __forceinline__ void pw_issue_a(const LinPWParams& p, char* smem, int slot, int wave, int lane, int ks, const PwAddr& ad) {
     using G = PwGeo<TN>;
     const bool second = ks >= p.kt0;
     // (ONE descriptor from selected scalars: a select between two descriptors becomes a branch whose join drains the ring)
     const void* abase = second ? p.a1 : p.a;
     const unsigned abytes = second ? p.a1_bytes : p.a_bytes;
+    const int c = second ? p.c1 : p.c0;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(abase), 0, abytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
-    const int soff_a = (second ? ks - p.kt0 : ks) * 64, soff_w = ks * 64;
+    const int soff = (second ? ks - p.kt0 : ks) * 128;
     char* stage = smem + slot * G::STAGE;
+    const unsigned v = second ? ad.a1 : ad.a0;
+    const int row = wave * 8 + (lane >> 3);
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(stage + (wave + PW_NW * it) * 1024), 16,
-                                                 second ? ao[1][it] : ao[0][it], soff_a, 0, 0);
+    for (int it = 0; it < G::A_IT; ++it) {
+        const unsigned off = (ad.valid && ad.m0 + row + 64 * it < p.M) ? v : kPwOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(stage + (wave + PW_NW * it) * 1024), 16, off,
+                                                 soff + it * 128 * c, 0, 0);
+    }
+}
+template <int TN>
+__device__ __forceinline__ void pw_issue_w(const LinPWParams& p, char* smem, int slot, int wave, int ks, const PwAddr& ad) {
+    using G = PwGeo<TN>;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const int soff = ks * 128;
+    char* stage = smem + slot * G::STAGE + G::A_SLOT;
 #pragma unroll
     for (int it = 0; it < G::W_IT; ++it) {
-        const int q = wave + PW_NW * it;
-        char* dst = q < G::W_PIECES ? stage + G::A_SLOT + q * 1024 : smem + G::DUMMY;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)dst, 16, bo[it], soff_w, 0, 0);
+        // (n_pad is a multiple of 64 = the row stride of the pieces: a piece is inside the packed weight or outside as a whole)
+        const unsigned off = (ad.valid && ad.n0 + 64 * it < p.n_pad) ? ad.w : kPwOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(stage + (wave + PW_NW * it) * 1024), 16, off,
+                                                 soff + it * 128 * p.K, 0, 0);
     }
 }
 
-// per-lane source offsets of this wave's DMA pieces for output tile (tm, tn): piece q covers tile rows 16q .. 16q+15 (64 bytes of K
-// each); a lane fetches the 16-byte chunk that belongs at its (linear) LDS position under the XOR swizzle.  valid == false: every
-// piece out of range (the ring keeps its cadence past the last tile: zeros into slots nobody reads)
 template <int TN>
-__device__ __forceinline__ void pw_offsets(const LinPWParams& p, bool valid, int tm, int tn, int wave, int lane, unsigned (&ao)[2][2],
-                                           unsigned (&bo)[3]) {
+__device__ __forceinline__ void pw_offsets(const LinPWParams& p, bool valid, int tm, int tn, int wave, int lane, PwAddr& ad) {
     using G = PwGeo<TN>;
-    const int cp = lane & 3, rsub = lane >> 2;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int row = (wave + PW_NW * it) * 16 + rsub;
-        const int m = tm * PW_BM + row;
-        const unsigned chunk = (unsigned)((cp ^ ((row >> 2) & 3)) * 8);
-        ao[0][it] = (valid && m < p.M) ? ((unsigned)m * (unsigned)p.c0 + chunk) * 2u : kPwOob;
-        ao[1][it] = (valid && m < p.M) ? ((unsigned)m * (unsigned)p.c1 + chunk) * 2u : kPwOob;
+    const int slot = lane & 7, rsub = lane >> 3;
+    const int row = wave * 8 + rsub;
+    const unsigned chunk = (unsigned)((slot ^ ((row >> 1) & 7)) * 8);
+    const int m = tm * PW_BM + row, n = tn * G::BN + row;
+    ad.a0 = ((unsigned)m * (unsigned)p.c0 + chunk) * 2u;
+    ad.a1 = ((unsigned)m * (unsigned)p.c1 + chunk) * 2u;
+    ad.w = ((unsigned)n * (unsigned)p.K + chunk) * 2u;
+    ad.m0 = tm * PW_BM;
+    ad.n0 = tn * G::BN;
+    ad.valid = valid;
+}
+
+// byte offset (into the torch-layout bias) of packed columns 4t .. 4t+3 of tile column tn, out of range past the tile / the layer
+template <int TN>
+__device__ __forceinline__ unsigned pw_bias_off(const LinPWParams& p, bool geglu, bool valid, int tn, int t) {
+    using G = PwGeo<TN>;
+    const int pc = tn * G::BN + 4 * t;
+    int oc = pc;
+    if (geglu) {
+        const int blk = pc >> 5, w = pc & 31;
+        oc = ((blk & 1) ? p.n_dst : 0) + (blk >> 1) * 32 + w;
     }
-#pragma unroll
-    for (int it = 0; it < G::W_IT; ++it) {
-        const int q = wave + PW_NW * it;
-        const int row = q * 16 + rsub;
-        const int n = tn * G::BN + row;
-        const unsigned chunk = (unsigned)((cp ^ ((row >> 2) & 3)) * 8);
-        bo[it] = (valid && q < G::W_PIECES && n < p.n_pad) ? ((unsigned)n * (unsigned)p.K + chunk) * 2u : kPwOob;
-    }
+    return (valid && 4 * t < G::BN && pc < p.n_out) ? (unsigned)oc * 4u : kPwOob;
 }
 
 // bias of the BN packed columns of tile column tn: thread t fetches packed columns 4t .. 4t+3 (zeros past the tile / without a bias)
@@ -147,20 +182,18 @@ __device__ __forceinline__ u32x4 pw_load_bias(const LinPWParams& p, bool geglu, 
     return __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
 }
 
-__device__ __forceinline__ u32x4 pw_load_res(const LinPWParams& p, unsigned off) {
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, p.res_bytes, 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
-}
-
-// two 16-byte stores the compiler's wait-count bookkeeping does not see (header).  Store data is read at issue on gfx9, but over
-// several cycles: a VALU write of the data registers within 2 wait states of a > 8-byte store corrupts it -- the nop is inside
+// two 16-byte stores the compiler's wait-count bookkeeping does not see (header).  Every asm VMEM statement opens with `s_nop 4`: its
+// descriptor lives in SGPRs that hipcc may have just reloaded from a spill lane (v_readlane = a VALU write of an SGPR), and a VMEM
+// instruction reading such an SGPR within 5 wait states is a hazard nobody pads inside an asm string (found as wrong tiles in the
+// kernels with SGPR spills).  Store data is read at issue on gfx9, but over several cycles: a VALU write of the data registers within 2
+// wait states of a > 8-byte store corrupts it -- the closing nop.
 template <bool NT>
 __device__ __forceinline__ void pw_store2(const u32x4& rdst, const u32x4& d0, unsigned o0, const u32x4& d1, unsigned o1) {
     if constexpr (NT)
-        asm volatile("buffer_store_dwordx4 %0, %1, %4, 0 offen nt\n\tbuffer_store_dwordx4 %2, %3, %4, 0 offen nt\n\ts_nop 2"
+        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %4, 0 offen nt\n\tbuffer_store_dwordx4 %2, %3, %4, 0 offen nt\n\ts_nop 2"
                      ::"v"(d0), "v"(o0), "v"(d1), "v"(o1), "s"(rdst) : "memory");
     else
-        asm volatile("buffer_store_dwordx4 %0, %1, %4, 0 offen\n\tbuffer_store_dwordx4 %2, %3, %4, 0 offen\n\ts_nop 2"
+        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %4, 0 offen\n\tbuffer_store_dwordx4 %2, %3, %4, 0 offen\n\ts_nop 2"
                      ::"v"(d0), "v"(o0), "v"(d1), "v"(o1), "s"(rdst) : "memory");
 }
 
@@ -172,26 +205,27 @@ __device__ __forceinline__ unsigned pw_off(unsigned row, int col, int n_dst) {
     return (row != kPwRowNone && col < n_dst) ? row + (unsigned)col * 2u : kPwOob;
 }
 
-// walks the tiles of a workgroup (all wave-uniform)
+// Walks the tiles of a workgroup (all wave-uniform).  XCD x owns row blocks [x * m_per, (x+1) * m_per) and all column tiles; its gm * gn
+// workgroups cover one gm x gn BLOCK of tiles per round (workgroup lid: row lid % gm, column lid / gm of the block), column chunks
+// fastest: the workgroups an XCD runs at the same time share gm activation row blocks and gn weight panels in its L2 (with one row of
+// 32 column tiles in flight the 6.5 MB weight of the level-1 GEGLU projection streamed through the 4 MB L2 once per row block), and a
+// workgroup's consecutive tiles re-read ITS row block while it is still there.
 struct PwTileIter {
-    int q, tm, tn, left;       // unit, tile coordinates, tiles left in the unit after this one
+    int r, tm, tn;
     bool valid;
-    __device__ __forceinline__ void set(const LinPWParams& p, int unit, int m_lo, int n_units) {
-        q = unit;
-        valid = unit < n_units;
-        const int rb = unit / p.nch, ch = unit - rb * p.nch;
-        tm = m_lo + rb;
-        tn = ch * p.cpt;
-        left = min(p.cpt, p.tiles_n - tn) - 1;
-    }
-    __device__ __forceinline__ void advance(const LinPWParams& p, int wpx, int m_lo, int n_units) {
-        if (left > 0) { --left; ++tn; }
-        else set(p, q + wpx, m_lo, n_units);
+    __device__ __forceinline__ void set(const LinPWParams& p, int r0, int lm, int ln, int m_lo, int m_cnt, int rounds) {
+        valid = false;
+        for (r = r0; r < rounds; ++r) {
+            const int sm = r / p.nbn, cn = r - sm * p.nbn;
+            const int tml = sm * p.gm + lm;
+            tn = cn * p.gn + ln;
+            if (tml < m_cnt && tn < p.tiles_n) { tm = m_lo + tml; valid = true; break; }
+        }
     }
 };
 
 // one 32 x 32 block (GEGLU: one value / gate pair) of the finished tile -> two packed 16-byte chunks.  c[k]: the lane's 16 columns
-// in output order (registers 0..7 = columns 8h .. 8h+7, 8..15 = 16 + 8h .. of the block).  RESV: residual chunks of the same columns
+// in output order (registers 0..7 = columns 8h .. 8h+7, 8..15 = 16 + 8h .. of the block).  RES: residual chunks of the same columns
 template <typename T, bool RES>
 __device__ __forceinline__ void pw_pack(const float (&c)[16], float scale, const u32x4 (&res)[2], u32x4 (&out)[2]) {
 #pragma unroll
@@ -225,72 +259,92 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
     const int hi = lane >> 5, l31 = lane & 31;
     const int prm = pw_perm(l31);
 
-    // tiles of this workgroup (the walk of linear_pp.hip): XCD x owns row blocks [x * m_per, (x+1) * m_per), cut into units of up to
-    // `cpt` consecutive column tiles; the XCD's workgroups take its units round-robin, row block major
-    const int xcd = blockIdx.x & 7, lid = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, lid = blockIdx.x >> 3;
     const int m_lo = xcd * p.m_per, m_cnt = min(p.tiles_m, m_lo + p.m_per) - m_lo;
-    const int n_units = m_cnt > 0 ? m_cnt * p.nch : 0;
-    if (lid >= n_units) return;
+    const int rounds = m_cnt > 0 ? ((m_cnt + p.gm - 1) / p.gm) * p.nbn : 0;
+    const int lm = lid % p.gm, ln = lid / p.gm;
     PwTileIter cur, nxt, iss;                    // compute side, the tile after it, issue side (newest ring step in flight)
-    cur.set(p, lid, m_lo, n_units);
-    nxt = cur; nxt.advance(p, wpx, m_lo, n_units);
+    cur.set(p, 0, lm, ln, m_lo, m_cnt, rounds);
+    if (!cur.valid) return;
+    nxt.set(p, cur.r + 1, lm, ln, m_lo, m_cnt, rounds);
     iss = cur;
 
     u32x4 rdst;
     rdst[0] = (unsigned)(uintptr_t)p.dst; rdst[1] = (unsigned)((uintptr_t)p.dst >> 32) & 0xFFFFu; rdst[2] = p.dst_bytes; rdst[3] = 0x00020000u;
 
-    // fragment read offsets inside a ring slot (bytes): row * 64 + swizzled chunk; k-sub-step kk = 0, 1 of the step's 32 K values
-    int a_off[2], w_off[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        a_off[kk] = (wm * 64 + l31) * 64 + (((kk * 2 + hi) ^ ((l31 >> 2) & 3)) << 4);
-        w_off[kk] = G::A_SLOT + (wn * 32 * TN + prm) * 64 + (((kk * 2 + hi) ^ ((prm >> 2) & 3)) << 4);
-    }
+    // fragment read offsets inside a ring slot (bytes): row * 128 + swizzled chunk of k-sub-step 0; sub-step kk: XOR kk << 5
+    const int a_off = (wm * 64 + l31) * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4);
+    const int w_off = G::A_SLOT + (wn * 32 * TN + prm) * 128 + ((hi ^ ((prm >> 1) & 7)) << 4);
 
     f32x16 acc[2][TN];
-    unsigned ao[2][2], bo[3];   // (fixed bound: a dependent one in the helpers' signatures fails substitution in hipcc's host pass)
-    int ks_i = 2;                                // issue side: K-step of the newest ring step in flight
+    PwAddr ad;
+    int ks_i = 1;                                // issue side: K-step of the newest ring step in flight
     const int kT = p.k_steps;
 
-    // ---- prologue: steps 0..2 of the first tile, its bias slab ----
+    // ---- prologue: steps 0 and 1 of the first tile (the whole ring), its bias slab ----
     {
-        pw_offsets<TN>(p, true, cur.tm, cur.tn, wave, lane, ao, bo);
-        pw_issue<TN>(p, smem, 0, wave, 0, ao, bo);
-        pw_issue<TN>(p, smem, 1, wave, 1, ao, bo);
-        pw_issue<TN>(p, smem, 2, wave, 2, ao, bo);
+        pw_offsets<TN>(p, true, cur.tm, cur.tn, wave, lane, ad);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            pw_issue_a<TN>(p, smem, g, wave, lane, g, ad);
+            pw_issue_w<TN>(p, smem, g, wave, g, ad);
+        }
         const u32x4 b = pw_load_bias<TN>(p, GEGLU, true, cur.tn, tid);
         __builtin_amdgcn_s_waitcnt(pw_wait(0));
         if (4 * tid < G::BN) *reinterpret_cast<u32x4*>(smem + G::SLAB + tid * 16) = b;
     }
     int rs = 0;                                  // ring slot the current step reads
 
-// top of a step: (from step 3 on) the step's operands have landed -- everything but the two newest steps' pieces --, every wave is
-// done with the slot the next pieces go to
-#define PW_ISSUE_NEXT()                                                                   \
-    {                                                                                     \
-        if (++ks_i == kT) {                                                               \
-            ks_i = 0;                                                                     \
-            iss.advance(p, wpx, m_lo, n_units);                                           \
-            pw_offsets<TN>(p, iss.valid, iss.tm, iss.tn, wave, lane, ao, bo);             \
-        }                                                                                 \
-        pw_issue<TN>(p, smem, (rs + 3) & 3, wave, ks_i, ao, bo);                          \
+// One K-step (64 of K) = four sub-steps of 16.  A sub-step runs the 2 * TN MFMAs of its fragments column by column (two row blocks per
+// W fragment) and, between the columns, fetches the NEXT sub-step's fragments one column ahead -- a W fragment's registers are free as
+// soon as its two MFMAs are issued, so about TN + 1 W fragments are live instead of two full sets (two sets beside 160 accumulators
+// spilled).  In front of sub-step 3 every fragment of step g is in registers: the wave waits for step g+1's pieces (WAIT_) and its own
+// LDS reads, the barrier publishes step g+1 and RETIRES step g's slot, and sub-step 3 refills it at once with the pieces of step g+2
+// (activation rows after column 0, weight rows after column 2) while it fetches the kk = 0 fragments of step g+1 under its MFMAs.
+#define PW_SUB(ca_, cw_, na_, nw_, NEXT_, nslot_, nkk_, DMA_)                                                     \
+    {                                                                                                             \
+        const char* st_ = smem + (nslot_) * G::STAGE;                                                             \
+        const int ao_ = a_off ^ ((nkk_) << 5), wo_ = w_off ^ ((nkk_) << 5);                                       \
+        if (NEXT_) {                                                                                              \
+            na_[0] = pw_frag<T>(st_ + ao_);                                                                       \
+            na_[1] = pw_frag<T>(st_ + ao_ + 4096);                                                                \
+            nw_[0] = pw_frag<T>(st_ + wo_);                                                                       \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            acc[0][j] = PwMma<T>::mma(cw_[j], ca_[0], acc[0][j]);                                                 \
+            acc[1][j] = PwMma<T>::mma(cw_[j], ca_[1], acc[1][j]);                                                 \
+            if (NEXT_ && j + 1 < TN) nw_[j + 1] = pw_frag<T>(st_ + wo_ + (j + 1) * 4096);                         \
+            if (DMA_ && j == 0) {                                                                                 \
+                if (++ks_i == kT) {                                                                               \
+                    ks_i = 0;                                                                                     \
+                    iss.set(p, iss.r + 1, lm, ln, m_lo, m_cnt, rounds);                                           \
+                    pw_offsets<TN>(p, iss.valid, iss.tm, iss.tn, wave, lane, ad);                                 \
+                }                                                                                                 \
+                pw_issue_a<TN>(p, smem, rs, wave, lane, ks_i, ad);                                                \
+            }                                                                                                     \
+            if (DMA_ && j == 2) pw_issue_w<TN>(p, smem, rs, wave, ks_i, ad);                                      \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
     }
-// the 4 * TN MFMAs of a step (transposed product: the W fragment is the A operand)
-#define PW_COMPUTE()                                                                      \
-    {                                                                                     \
-        const char* st = smem + rs * G::STAGE;                                            \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                \
-            Frag fa[2], fw[TN];                                                           \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) fa[i] = pw_frag<T>(st + a_off[kk] + i * 2048);   \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) fw[j] = pw_frag<T>(st + w_off[kk] + j * 2048);  \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)   \
-                acc[i][j] = PwMma<T>::mma(fw[j], fa[i], acc[i][j]);                       \
-        }                                                                                 \
-        rs = (rs + 1) & 3;                                                                \
+#define PW_STEP(LAST_, WAIT_)                                                                                     \
+    {                                                                                                             \
+        PW_SUB(fa0, fw0, fa1, fw1, true, rs, 1, false)                                                            \
+        PW_SUB(fa1, fw1, fa0, fw0, true, rs, 2, false)                                                            \
+        PW_SUB(fa0, fw0, fa1, fw1, true, rs, 3, false)                                                            \
+        __builtin_amdgcn_s_waitcnt(WAIT_);                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        PW_SUB(fa1, fw1, fa0, fw0, !(LAST_), rs ^ 1, 0, true)                                                     \
+        rs ^= 1;                                                                                                  \
     }
+    Frag fa0[2], fw0[TN], fa1[2], fw1[TN];
+    constexpr int kWaitLds = 0xC07F;                             // lgkmcnt(0) only
+    constexpr int kWaitFirst = pw_wait(4 * NOUT) & ~0x0F00;      // step 1 of the tile has landed: everything but the previous epilogue's 4 * NOUT stores
+    constexpr int kWaitStep = pw_wait(0) & ~0x0F00;              // vmcnt(0) lgkmcnt(0): step g+1 has landed (and every older store)
 
-    for (; cur.valid; cur = nxt, nxt.advance(p, wpx, m_lo, n_units)) {
-        // ---- step 0: the tile starts from its bias (slab written in the prologue / the previous epilogue, published by this barrier) ----
+    for (; cur.valid; cur = nxt, nxt.set(p, nxt.r + 1, lm, ln, m_lo, m_cnt, rounds)) {
+        // ---- the tile starts from its bias (slab written in the prologue / the previous epilogue, published by this barrier).  Steps 0
+        //      and 1 found their pieces retired by the epilogue's (the prologue's) load wait ----
         __builtin_amdgcn_s_barrier();
         {
             const float* slab = reinterpret_cast<const float*>(smem + G::SLAB) + wn * 32 * TN + 8 * hi;
@@ -303,23 +357,26 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
                     for (int e = 0; e < 4; ++e) { acc[0][j][4 * a + e] = b[e]; acc[1][j][4 * a + e] = b[e]; }
                 }
         }
-        PW_ISSUE_NEXT()
-        PW_COMPUTE()
-        // ---- steps 1, 2: their pieces were retired by the previous epilogue's (the prologue's) load wait ----
-        __builtin_amdgcn_s_barrier();
-        PW_ISSUE_NEXT()
-        PW_COMPUTE()
-        __builtin_amdgcn_s_barrier();
-        PW_ISSUE_NEXT()
-        PW_COMPUTE()
-        // ---- steps 3 .. kT-1 ----
-#pragma unroll 1
-        for (int ks = 3; ks < kT; ++ks) {
-            __builtin_amdgcn_s_waitcnt(pw_wait(2 * G::P));
-            __builtin_amdgcn_s_barrier();
-            PW_ISSUE_NEXT()
-            PW_COMPUTE()
+        {
+            const char* st0 = smem + rs * G::STAGE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa0[i] = pw_frag<T>(st0 + a_off + i * 4096);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fw0[j] = pw_frag<T>(st0 + w_off + j * 4096);
         }
+        PW_STEP(false, kWaitFirst)
+#pragma unroll 1
+        for (int ks = 1; ks < kT - 1; ++ks) PW_STEP(false, kWaitStep)
+        // Last step: nothing of the next tile is read before the epilogue.  The next tile's bias is requested here (inline asm: consumed
+        // in the epilogue behind a counted wait that leaves the ring pieces this step issues in flight -- the epilogue does not drain the ring)
+        u32x4 bnext;
+        {
+            u32x4 rbias;
+            rbias[0] = (unsigned)(uintptr_t)p.bias; rbias[1] = (unsigned)((uintptr_t)p.bias >> 32) & 0xFFFFu; rbias[2] = p.bias_bytes; rbias[3] = 0x00020000u;
+            const unsigned boff = pw_bias_off<TN>(p, GEGLU, nxt.valid, nxt.tn, tid);
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bnext) : "v"(boff), "s"(rbias));
+        }
+        PW_STEP(true, kWaitLds)
         // ---- epilogue: straight from the accumulators (header) ----
         {
             const int col0 = GEGLU ? (cur.tn * G::BN + wn * 32 * TN) >> 1 : cur.tn * G::BN + wn * 32 * TN;
@@ -337,20 +394,14 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
                 // invariants into the K loop).  Loads only are in flight here (stores last), VMEM returns in order: the wait in
                 // front of block b leaves the younger blocks of the window outstanding.  The next tile's bias rides in front.
                 constexpr int NB = 2 * TN;
-                u32x4 rres, rbias;
+                u32x4 rres;
                 rres[0] = (unsigned)(uintptr_t)p.residual; rres[1] = (unsigned)((uintptr_t)p.residual >> 32) & 0xFFFFu; rres[2] = p.res_bytes; rres[3] = 0x00020000u;
-                rbias[0] = (unsigned)(uintptr_t)p.bias; rbias[1] = (unsigned)((uintptr_t)p.bias >> 32) & 0xFFFFu; rbias[2] = p.bias_bytes; rbias[3] = 0x00020000u;
-                u32x4 bnext, r[NB][2];
-                {
-                    const int pc = nxt.tn * G::BN + 4 * tid;
-                    const unsigned boff = (nxt.valid && 4 * tid < G::BN && pc < p.n_out) ? (unsigned)pc * 4u : kPwOob;
-                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bnext) : "v"(boff), "s"(rbias));
-                }
+                u32x4 r[NB][2];
 #define PW_RES_ISSUE(b_)                                                                                                        \
     if constexpr ((b_) < NB) {                                                                                                  \
         const unsigned o0_ = pw_off(row_res[(b_) / TN], col0 + 32 * ((b_) % TN) + 8 * hi, p.n_dst);                             \
         const unsigned o1_ = pw_off(row_res[(b_) / TN], col0 + 32 * ((b_) % TN) + 16 + 8 * hi, p.n_dst);                        \
-        asm volatile("buffer_load_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen"                       \
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen"             \
                      : "=&v"(r[(b_) < NB ? (b_) : 0][0]), "=&v"(r[(b_) < NB ? (b_) : 0][1]) : "v"(o0_), "v"(o1_), "s"(rres));   \
     }
 #define PW_RES_BLOCK(b_)                                                                                                        \
@@ -376,8 +427,8 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
 #undef PW_RES_ISSUE
 #undef PW_RES_BLOCK
             } else {
-                const u32x4 bnext = pw_load_bias<TN>(p, GEGLU, nxt.valid, nxt.tn, tid);
-                __builtin_amdgcn_s_waitcnt(pw_wait(0));
+                // (the bias is older than the P ring pieces the last step issued: they stay in flight)
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(bnext) : "n"(G::P));
                 // (every wave has read the current slab long ago: at its step 0, barriers since)
                 if (4 * tid < G::BN) *reinterpret_cast<u32x4*>(smem + G::SLAB + tid * 16) = bnext;
 #pragma unroll
@@ -387,7 +438,7 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
                         float c[16];
                         if constexpr (GEGLU) {
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) c[k] = acc[i][2 * j][k] * gelu_erf_fast(acc[i][2 * j + 1][k]);
+                            for (int k = 0; k < 16; ++k) c[k] = acc[i][2 * j][k] * PW_GELU(acc[i][2 * j + 1][k]);
                         } else {
 #pragma unroll
                             for (int k = 0; k < 16; ++k) c[k] = acc[i][j][k];
@@ -407,8 +458,8 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
     }
     // (the ring pieces issued past the last tile are out of range: zeros into slots nobody reads; nothing to drain but the stores,
     //  which the end of the program waits for)
-#undef PW_ISSUE_NEXT
-#undef PW_COMPUTE
+#undef PW_SUB
+#undef PW_STEP
 }
 
 bool linear_pw_applicable(const mvldm_igemm_desc& d) {
@@ -441,10 +492,10 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     MVLDM_REQUIRE(linear_pw_applicable(d), "igemm: tile 13 (persistent wide Linear) does not apply to this problem");
     LinPWParams p;
     p.a = d.src0; p.a1 = d.src1; p.w = d.weight; p.bias = d.bias; p.residual = d.residual; p.dst = d.dst;
-    p.M = d.n_img * d.h_out * d.w_out; p.K = d.c0 + d.c1; p.c0 = d.c0; p.c1 = d.c1; p.kt0 = d.c0 / 32; p.n_out = d.n_out; p.n_pad = d.n_pad;
+    p.M = d.n_img * d.h_out * d.w_out; p.K = d.c0 + d.c1; p.c0 = d.c0; p.c1 = d.c1; p.kt0 = d.c0 / 64; p.n_out = d.n_out; p.n_pad = d.n_pad;
     p.n_dst = d.epilogue == MVLDM_EPI_GEGLU ? d.n_out / 2 : d.n_out;
     p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
-    p.k_steps = p.K / 32; p.out_scale = d.out_scale;
+    p.k_steps = p.K / 64; p.out_scale = d.out_scale;
     // 256 x 320 when the packed width is a multiple of 320 (every channel count of this UNet), else 256 x 256; GEGLU pairs need an even
     // number of column blocks per wave
     const bool geglu = d.epilogue == MVLDM_EPI_GEGLU;
@@ -458,7 +509,9 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     p.bias_bytes = d.bias ? (unsigned)d.n_out * 4u : 0u;
     p.res_bytes = d.residual ? (unsigned)((double)p.M * p.n_dst * 2.0) : 0u;
     p.dst_bytes = (unsigned)((double)p.M * p.dst_ld * 2.0);
-    p.nt_store = stream_stores((size_t)p.M * (size_t)p.n_dst * 2);
+    // write-back stores unless forced (header): MVLDM_STREAM_STORES=1 is the A/B knob
+    static const int kNt = getenv("MVLDM_STREAM_STORES") ? atoi(getenv("MVLDM_STREAM_STORES")) : 0;
+    p.nt_store = kNt == 1;
     if (kPwFake & 1) p.a_bytes = p.a1_bytes = 0;
     if (kPwFake & 2) p.w_bytes = 0;
     if (kPwFake & 4) p.dst_bytes = 0;
@@ -471,19 +524,27 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
         else
             n_cu = 256;
     }
-    // workgroups per XCD: one per CU, fewer when the busiest XCD has fewer tiles.  Unit length: the most consecutive column
-    // tiles (= L2 hits on the activation rows) for which the row blocks in flight on an XCD -- ceil(wpx / units per row block)
-    // + 1 of 256 x K x 2 bytes -- stay within about half of its 4 MB L2
-    const int wpx = std::max(1, std::min(n_cu / 8, p.m_per * p.tiles_n));
-    const double rb_bytes = 256.0 * p.K * 2.0;
-    p.cpt = 1;
-    for (int c = p.tiles_n; c >= 1; --c) {
-        const int nch = (p.tiles_n + c - 1) / c;
-        if (((wpx + nch - 1) / nch + 1) * rb_bytes <= 2.0e6) { p.cpt = c; break; }
-    }
-    if (kPwCpt > 0) p.cpt = std::min(kPwCpt, p.tiles_n);
-    p.nch = (p.tiles_n + p.cpt - 1) / p.cpt;
-    p.cpt = (p.tiles_n + p.nch - 1) / p.nch;                    // even units
+    // An XCD's workgroups (one per CU, fewer when it has fewer tiles) cover gm x gn blocks of tiles, round after round: the shape with
+    // (within 3 % of) the fewest rounds that moves the fewest bytes into the XCD's L2 per round -- gm activation row blocks + gn weight panels
+    const int cu_x = std::max(1, n_cu / 8);
+    const double a_t = 256.0 * p.K * 2.0, w_t = (double)bn * p.K * 2.0;
+    int best_rounds = 1 << 30;
+    for (int gm = 1; gm <= std::min(cu_x, p.m_per); ++gm)
+        for (int gn = 1; gn <= std::min(cu_x / gm, p.tiles_n); ++gn)
+            best_rounds = std::min(best_rounds, ((p.m_per + gm - 1) / gm) * ((p.tiles_n + gn - 1) / gn));
+    double best_cost = 1e300;
+    p.gm = p.gn = 1;
+    for (int gm = 1; gm <= std::min(cu_x, p.m_per); ++gm)
+        for (int gn = 1; gn <= std::min(cu_x / gm, p.tiles_n); ++gn) {
+            const int r = ((p.m_per + gm - 1) / gm) * ((p.tiles_n + gn - 1) / gn);
+            if (r > best_rounds * 1.03) continue;
+            const double cost = gm * a_t + gn * w_t;
+            if (cost < best_cost) { best_cost = cost; p.gm = gm; p.gn = gn; }
+        }
+    static const int kForceGm = getenv("MVLDM_PW_GM") ? atoi(getenv("MVLDM_PW_GM")) : 0;   // tuning: force the block shape
+    if (kForceGm > 0) { p.gm = std::min(std::min(kForceGm, cu_x), p.m_per); p.gn = std::max(1, std::min(cu_x / p.gm, p.tiles_n)); }
+    p.nbn = (p.tiles_n + p.gn - 1) / p.gn;
+    const int wpx = p.gm * p.gn;
     const int grid = 8 * wpx;
     const bool res = d.residual != nullptr;
     return dispatch_dtype(d.act_dtype, [&](auto t) -> int {
