@@ -3,6 +3,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scenes B] [--dtype bf16|f16|f32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+A plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts that torchrun command itself as a child process --
+before this process has touched the GPU -- and forwards its JSON line and exit code; a rank count that does not match --gpus is an error.
 
 Workload (BASELINE.json configs[1]): B scenes x (1 context + 4 target views) at 256x256 (latents
 32x32), 50 DDIM steps with classifier-free guidance 3.0 (=> two UNet passes per step, executed as ONE
@@ -170,6 +172,10 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
            "config": {"workload": f"configs[3]: optimizer step = {acc} micro-batches of {b} scenes x (1 ctx + 3 tgt) @ {args.res}x{args.res} per GPU: VAE "
                                   "encode, add_noise, UNet fwd+bwd (SD-2.1 topology + 9 multi-view blocks), MSE, clip 0.1, AdamW (fp32 master weights)",
                       "accumulation": "one plan per window (both micro-batches in one forward / backward)" if window else "one plan run per micro-batch",
+                      "draws": "FIXED shape: every micro-batch keeps its context view and its conditioning (index=1, unconditional=False), i.e. one recorded "
+                               "plan serves every window.  The reference draws the context count and a 10 % CFG drop per micro-batch "
+                               "(diffusion_wrapper.py:336,381): a randomised run meets up to S^2 window shapes, each recorded (and tuned) on first "
+                               "use, at most MVLDM_TRAIN_MAX_PLANS (4) kept -- this number is the steady state of one shape, not that mix",
                       "scenes_per_gpu": b, "params": n_params, "trained_params": int(tr.flat.numel),
                       "parallelism": f"data parallel x{world}: ZeRO-1 reduce-scatter + all-gather" if world > 1 else "single GPU"},
            "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)], "grad_norm": round(float(tr.opt.norm[0]), 4)}
@@ -201,6 +207,101 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
     return out
 
 
+def other_configs(args, den, vae, dev, two_roof):
+    """short legs for the BASELINE.json configs that are not `value`: configs[2] (ONE scene, 80-frame trajectory, anchored sampling with
+    num_anchors_views = 4, 25 DDIM steps -- the harness path of mv_ldm_amd.generate) and configs[4] (8 scenes x (1 ctx + 8 tgt) views
+    @ 512x512, f16, 50 DDIM steps, one sample).  Each with the per-layer two-roof bound of the plans it ran."""
+    import mv_ldm_amd
+    from mv_ldm_amd import generate as G
+    from mv_ldm_amd.pipeline import MVLDMPipeline, SamplerCfg
+    from mv_ldm_amd.scheduler import DDIMScheduler
+    res = {}
+    # ---- configs[2]
+    cfg = G.merge_config(G.DEFAULT_CONFIG, {"test": {"sampling_mode": "anchored", "num_anchors_views": 4}, "seed": 7})
+    cfg["model"]["scheduler"]["num_inference_steps"] = 25
+    pipe2 = MVLDMPipeline(den, vae, DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, 25))
+    pipe2.set_timesteps(25)
+    ex = [G.synthetic_example(0, 80, args.res, 7)]
+    r = G.evaluate(cfg, ex, pipe=pipe2, batch_scenes=1, warmup=True)       # (warm-up: the plans of both call shapes, untimed)
+    r = G.evaluate(cfg, ex, pipe=pipe2, batch_scenes=1)
+    bound = 0.0
+    for key, st in pipe2._plans.items():
+        st["plan"].profile(1)
+        pms = st["plan"].profile(2)
+        tr = two_roof(st["plan"].meta, pms)
+        st["_two_roof"] = tr
+    # (every sample() call of the schedule replays one of these plans 25 times; calls by shape)
+    from mv_ldm_amd.schedules import anchored_schedule
+    e = ex[0]
+    calls = anchored_schedule(e["context"]["index"][0].tolist(), e["context"]["extrinsics"][0], e["target"]["index"][0].tolist(),
+                              e["target"]["extrinsics"][0], num_anchors_views=4, ctx_intrinsics=e["context"]["intrinsics"][0],
+                              tgt_intrinsics=e["target"]["intrinsics"][0])
+    for c in calls:
+        v_c, v_t = len(c.ctx_index), len(c.tgt_index)
+        for key, st in pipe2._plans.items():
+            if key[0] == 1 and key[1] == v_c and key[2] == v_t:
+                bound += 25 * st["_two_roof"]["bound_ms"]
+                break
+    res["configs[2]"] = {"workload": f"1 scene, {len(r['frames'][ex[0]['scene'][0]])} target frames @ {args.res}x{args.res}, anchored sampling (num_anchors_views=4), "
+                                     f"25 DDIM steps, CFG 3.0, {args.dtype}, {r['sample_calls']} sample() calls incl. VAE encode / decode",
+                         "views_per_s": round(r["views"] / r["seconds"], 3), "seconds": round(r["seconds"], 3), "views": r["views"],
+                         "two_roof": {"bound_ms": round(bound, 2), "measured_ms": round(1e3 * r["seconds"], 1),
+                                      "frac": round(bound / (1e3 * r["seconds"]), 4), "note": "UNet plans only in the bound; VAE + host schedule in the measured time"}}
+    pipe2._plans.clear()
+    # ---- configs[4]
+    with mv_ldm_amd.compute_dtype(torch.float16):
+        pipe4 = MVLDMPipeline(den, vae, DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, 50))
+        pipe4.set_timesteps(50)
+        b4 = synthetic_batch(8, 1, 8, 512, 1234, dev)
+        pipe4.sample(b4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img4, _ = pipe4.sample(b4)
+        torch.cuda.synchronize()
+        s4 = time.perf_counter() - t0
+        assert torch.isfinite(img4).all()
+        st4 = pipe4.prepare(b4)
+        st4["plan"].profile(1)
+        tr4 = two_roof(st4["plan"].meta, st4["plan"].profile(2))
+    res["configs[4]"] = {"workload": "8 scenes x (1 ctx + 8 tgt) @ 512x512 (64x64 latents), 50 DDIM steps, CFG 3.0, f16, VAE encode + decode, 1 sample",
+                         "views_per_s": round(8 * 8 / s4, 3), "sample_s": round(s4, 3), "ddim_step_ms_eager_sum": tr4["measured_ms"],
+                         "two_roof": tr4, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    pipe4._plans.clear()
+    return res
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: run the N ranks as children of `torch.distributed.run` (one process per GPU,
+    rendezvous on 127.0.0.1) and pass their output through.  Called before anything has initialised the GPU in THIS process (a
+    process that has must never exec or hand its device to another program); the children are fresh interpreters."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    for ln in lines:
+        print(ln, flush=True)
+    if proc.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank launch failed (exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    ok = False
+    for ln in lines:
+        try:
+            ok = ok or json.loads(ln).get("n_gpus") == args.gpus
+        except (ValueError, AttributeError):
+            pass
+    if not ok:
+        print(f"bench.py: no result line with n_gpus == {args.gpus} came back from the launch", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,12 +324,31 @@ def main():
                          "--scenes x 4 views, bf16, AdamW, clip 0.1; N > 1: ZeRO-1 reduce-scatter / all-gather over RCCL")
     ap.add_argument("--unet-pass-only", action="store_true",
                     help="run ONE eager UNet+DDIM pass and exit (the population `roofline` is quoted on; used for PMC passes)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin` leg (the reference's own loop shape: two forwards + scheduler step per DDIM step)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[2] / configs[4] legs (`other_configs`)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different rank count")
+    if os.environ.get("MVLDM_BENCH_DRYRUN") == "1":
+        # (test knob: the launch contract without a GPU -- rendezvous over gloo, barrier, one line from rank 0)
+        import torch.distributed as dist_
+        if world > 1:
+            dist_.init_process_group("gloo")
+            box = [None] * world
+            dist_.all_gather_object(box, rank)
+            assert sorted(box) == list(range(world))
+            dist_.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (launch contract only)", "n_gpus": world, "dryrun": True}), flush=True)
+        if world > 1:
+            dist_.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # (test knobs: MVLDM_BENCH_SHARE_GPU=1 puts every rank on device 0 and MVLDM_BENCH_BACKEND=gloo replaces RCCL, so
@@ -293,6 +413,14 @@ def main():
         torch.cuda.synchronize()
         return
 
+    from mv_ldm_amd import plan as P
+    if dist is not None and os.environ.get("MVLDM_AUTOTUNE", "1") != "0":
+        # every rank must freeze the SAME tiles (same kernels, same last-bit rounding on every rank): rank 0 records -- and thereby
+        # tunes -- its plans first, the others take its choices before they record theirs
+        if rank == 0:
+            pipe.sample(batch)
+            torch.cuda.synchronize()
+        P.broadcast_tune_cache(dist, src=0, device=dev if backend == "nccl" else None)
     for _ in range(args.warmup):
         pipe.sample(batch)
     barrier()
@@ -318,10 +446,11 @@ def main():
                                   "VAE encode ctx + decode 4 views", "scenes_per_gpu": b, "params": n_params,
                       "parallelism": f"scene-sharded x{world}, no collective"}}
 
-    from mv_ldm_amd import plan as P
     out["autotune"] = {"enabled": os.environ.get("MVLDM_AUTOTUNE", "1") != "0",
                        "note": "plan-time tile selection times candidates on this box (MVLDM_AUTOTUNE=0 keeps the rules): "
-                               "tile choice, hence last-bit rounding, can differ between boxes",
+                               "tile choice, hence last-bit rounding, can differ between boxes; the ranks of one job share rank 0's "
+                               "choices, MVLDM_TUNE_CACHE=<file> carries them to another process",
+                       "cache_file": os.environ.get("MVLDM_TUNE_CACHE"),
                        "problems_timed": len(P._TUNE_CACHE),
                        "frozen_tiles": {str(t): sum(1 for v in P._TUNE_CACHE.values() if v == t) for t in sorted(set(P._TUNE_CACHE.values()))}}
 
@@ -457,7 +586,7 @@ def main():
             # ---- the same workload in f16 -- the reference's own `16-mixed` arithmetic, the 16-bit type that meets the 1e-3
             # north-star tolerance (bf16 does not) -- timed here so that the tolerance-meeting precision has a number on the
             # same line, from the same process on the same box: whole `sample()`s incl. VAE encode + decode, like `value`
-            alt, alt_steps = torch.float16, 3
+            alt, alt_steps = torch.float16, 6
             with mv_ldm_amd.compute_dtype(alt):
                 pipe.sample(batch)                                   # records + tunes the f16 plans (UNet and VAE)
                 torch.cuda.synchronize()
@@ -481,7 +610,7 @@ def main():
                 "output stage run on the target views only.  Same values as the full walk (f32: 2e-6; tests/test_hip_headline.py); "
                 "`roofline` counts the FLOPs that are executed.  MVLDM_CFG_SHARE=0 MVLDM_TAIL_DROP=0 walks every image like the reference."}
     if world == 1 and not args.no_full_walk and out["exact_sharing"]["enabled"]:
-        # ---- the same workload with every image walked through every layer (what the reference's two forwards compute): 2 samples
+        # ---- the same workload with every image walked through every layer (what the reference's two forwards compute): 6 samples
         saved = {k: os.environ.get(k) for k in ("MVLDM_CFG_SHARE", "MVLDM_TAIL_DROP")}
         os.environ["MVLDM_CFG_SHARE"], os.environ["MVLDM_TAIL_DROP"] = "0", "0"
         kept = dict(pipe._plans)
@@ -490,12 +619,12 @@ def main():
             pipe.sample(batch)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(6):
                 img_f, _ = pipe.sample(batch)
             torch.cuda.synchronize()
-            fw_s = (time.perf_counter() - t0) / 2
+            fw_s = (time.perf_counter() - t0) / 6
             assert torch.isfinite(img_f).all()
-            out["exact_sharing"]["full_walk"] = {"value": round(b * v_t / fw_s, 3), "unit": "views/s", "steps": 2, "warmup": 1,
+            out["exact_sharing"]["full_walk"] = {"value": round(b * v_t / fw_s, 3), "unit": "views/s", "steps": 6, "warmup": 1,
                                                  "ms_per_step": round(1e3 * fw_s, 3)}
         finally:
             for k, v in saved.items():
@@ -505,6 +634,34 @@ def main():
                     os.environ[k] = v
             pipe._plans.clear()
             pipe._plans.update(kept)
+    if rank == 0 and world == 1 and not args.no_dropin:
+        # ---- INTEGRATION.md level A: the reference's own loop shape (diffusion_wrapper.py:455-490 calling :413-453) -- per DDIM step two
+        # `MultiViewUNet.forward` calls (conditional [1+4 views], unconditional [4]) from Python and one fused CFG + DDIM kernel --
+        # beside the fused sampler that replaces the loop (level B = `value`): what registering the classes in the reference's
+        # registries delivers without touching its loop
+        drop = {}
+        for sb, reps in ((1, 3), (b, 2)):
+            bt = batch if sb == b else synthetic_batch(sb, v_c, v_t, args.res, 1234, dev, scene_ids=list(range(sb)))
+            pipe.sample_literal(bt)                               # records + tunes the two forward plans of this shape
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                img_l, _ = pipe.sample_literal(bt)
+            torch.cuda.synchronize()
+            lit_s = (time.perf_counter() - t0) / reps
+            assert torch.isfinite(img_l).all()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pipe.sample(bt)
+            torch.cuda.synchronize()
+            fus_s = (time.perf_counter() - t0) / reps
+            drop[f"b{sb}"] = {"views_per_s": round(sb * v_t / lit_s, 3), "sample_ms": round(1e3 * lit_s, 2), "samples": reps,
+                              "fused_sampler_views_per_s": round(sb * v_t / fus_s, 3), "fused_over_dropin": round(lit_s / fus_s, 3)}
+        drop["what"] = ("pipeline.sample_literal: Python loop over the 50 timesteps, per step pipeline.step = model.forward(cond) + "
+                        "model.forward(uncond) + fused CFG/DDIM kernel; VAE encode + decode included; same process, same box as `value`")
+        out["dropin"] = drop
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        out["other_configs"] = other_configs(args, den, vae, dev, two_roof)
     if world == 1 and not args.no_train_line:
         # ---- the training step of the same path (BASELINE configs[3]; `python bench.py --train` is the full-length run).  Last
         # GPU work of the process: the fused AdamW updates the denoiser's weights in place.

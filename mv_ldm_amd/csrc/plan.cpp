@@ -213,6 +213,22 @@ extern "C" int mvldm_plan_run_range(mvldm_plan* p, int first, int last, mvldm_st
     static const bool serial = getenv("MVLDM_PLAN_SERIAL") && atoi(getenv("MVLDM_PLAN_SERIAL"));      // A/B knob: ignore the lane markers
     bool in_group = false;
     int lane = 0;
+    if (!serial) {
+        // validate the lane markers of the range BEFORE anything is launched: a cut inside a parallel group used to be noticed only
+        // after earlier ops (or the group's lanes) had been enqueued, leaving side-stream work unordered against `s`
+        bool open = false;
+        for (int i = first; i < last; ++i) {
+            const int k = p->ops[i].kind;
+            if (k == MVLDM_OP_PAR_BEGIN) {
+                MVLDM_REQUIRE(!open, "plan: nested parallel group at op %d", i);
+                open = true;
+            } else if (k == MVLDM_OP_PAR_NEXT || k == MVLDM_OP_PAR_END) {
+                MVLDM_REQUIRE(open, "plan: the range [%d, %d) starts inside a parallel group", first, last);
+                if (k == MVLDM_OP_PAR_END) open = false;
+            }
+        }
+        MVLDM_REQUIRE(!open, "plan: the range [%d, %d) ends inside a parallel group", first, last);
+    }
     for (int i = first; i < last; ++i) {
         const mvldm_op& op = p->ops[i];
         if (!serial && op.kind == MVLDM_OP_PAR_BEGIN) {

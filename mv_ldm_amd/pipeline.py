@@ -240,8 +240,10 @@ class MVLDMPipeline:
         # the target views cond_img of the conditional pass, and the context views' inputs (latents, mask 0, rays, timestep 0) do not
         # change during sampling -- the layers in front of the first multi-view block run once per STEP on one copy of every target
         # view and once per SAMPLE on the context views (`const_plan`, run by load_inputs after the loader plan).
+        # (v_c == 0, a context-free sample: both passes are the same images -- nothing to share, and the pairing of the first multi-view
+        #  block assumes context keys; the plain two-group walk handles it)
         dup, const_plan = None, None
-        if use_cfg and os.environ.get("MVLDM_CFG_SHARE", "1") != "0":
+        if use_cfg and v_c > 0 and os.environ.get("MVLDM_CFG_SHARE", "1") != "0":
             dup = (n_cond, cond_img)
             if os.environ.get("MVLDM_CFG_SHARE", "1") != "1a":
                 cb = Builder(dev, dtype, record=True)
@@ -355,9 +357,17 @@ class MVLDMPipeline:
         return (self.last_stage_decode(x0) if decode else None), x0
 
     def _sample_ancestral(self, batch, x_T, encode_noise, decode, dtype, step_generator, step_noise):
-        """`sample()` with `SCHEDULER["ddpm"]`: the reference's loop as written (diffusion_wrapper.py:455-490) -- per step the two
-        denoiser forwards (each one recorded plan), then CFG compose + ancestral update + fresh noise in one HIP kernel.  Not
-        captured into a single graph: every step draws new noise.  `step_noise`: [n_steps, b, v_t, c, hl, wl] explicit draws."""
+        """`sample()` with `SCHEDULER["ddpm"]`: the reference's loop as written -- not captured into a single graph: every step
+        draws new noise.  `step_noise`: [n_steps, b, v_t, c, hl, wl] explicit draws."""
+        return self.sample_literal(batch, x_T, encode_noise, decode, dtype, step_generator, step_noise)
+
+    def sample_literal(self, batch, x_T=None, encode_noise=None, decode: bool = True, dtype=None, step_generator=None, step_noise=None):
+        """The reference's `sample` AS WRITTEN (diffusion_wrapper.py:455-490): a Python loop over the timesteps calling `step`
+        (:413-453) -- per step the two denoiser forwards (conditional over [v_c + v_t] views, unconditional over [v_t]; each a
+        recorded plan behind `MultiViewUNet.forward`), then CFG compose + scheduler update in one HIP kernel.  This is what
+        registering the denoiser / scheduler / autoencoder in the reference's registries (INTEGRATION.md level A) executes; the
+        fused `sample()` is the level-B replacement of this loop.  Same result as `sample()` up to rounding (the fused sampler shares
+        the CFG prefix exactly: tests/test_hip_model.py)."""
         dtype = dtype or get_compute_dtype()
         ctx, tgt = batch["context"], batch["target"]
         dev = self.device

@@ -14,6 +14,7 @@ torch is only the allocator here (`torch.empty`) and the owner of the HIP stream
 from __future__ import annotations
 
 import ctypes as C
+import json
 import os
 from dataclasses import dataclass
 from typing import List, Optional
@@ -455,7 +456,57 @@ class Builder:
 # Results are cached per problem signature for the life of the process.  MVLDM_AUTOTUNE=0 keeps the rules;
 # MVLDM_TUNE_TILES=0,2,9,... restricts the candidates (the small 64x64 / 32x64 tiles only ever win below ~4 scenes: +2 % at b = 1).
 _TUNE_CACHE = {}
+_WGRAD_CACHE = {}
 _TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) if os.environ.get("MVLDM_TUNE_TILES") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)
+
+
+# ---- the tune cache as data: a file (MVLDM_TUNE_CACHE=<path>.json: read at import, rewritten whenever a plan timed new problems) and a
+# broadcast.  Every process times its candidates itself, so two ranks of a job -- or a profiler pass and the run it is meant to
+# explain -- can freeze different tiles (different last-bit rounding, and rocprof tables full of trial launches).  With the file a
+# second process records its plans WITHOUT a single trial launch; `broadcast_tune_cache` gives the ranks of a job rank 0's choices.
+def tune_cache_state() -> dict:
+    return {"version": 1, "igemm": {json.dumps(list(k)): int(v) for k, v in _TUNE_CACHE.items()},
+            "wgrad": {json.dumps(list(k)): int(v) for k, v in _WGRAD_CACHE.items()}}
+
+
+def set_tune_cache_state(state: dict, replace: bool = False) -> None:
+    if replace:
+        _TUNE_CACHE.clear()
+        _WGRAD_CACHE.clear()
+    for name, cache in (("igemm", _TUNE_CACHE), ("wgrad", _WGRAD_CACHE)):
+        for k, v in (state.get(name) or {}).items():
+            cache[tuple(json.loads(k))] = int(v)
+
+
+def save_tune_cache(path: Optional[str] = None) -> Optional[str]:
+    path = path or os.environ.get("MVLDM_TUNE_CACHE")
+    if not path:
+        return None
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        json.dump(tune_cache_state(), f, indent=0, sort_keys=True)
+    os.replace(tmp, path)           # atomic: ranks sharing one file never see half of it
+    return path
+
+
+def load_tune_cache(path: Optional[str] = None) -> int:
+    path = path or os.environ.get("MVLDM_TUNE_CACHE")
+    if not path or not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        set_tune_cache_state(json.load(f))
+    return len(_TUNE_CACHE) + len(_WGRAD_CACHE)
+
+
+def broadcast_tune_cache(dist, src: int = 0, device=None) -> None:
+    """every rank takes rank `src`'s tile choices (call it after `src` has recorded -- and thereby tuned -- its plans and before
+    the other ranks record theirs): the ranks of a job then run the same kernels on the same problems"""
+    box = [tune_cache_state() if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src, device=device)
+    set_tune_cache_state(box[0], replace=True)
+
+
+load_tune_cache()
 
 
 def _igemm_signature(d) -> tuple:
@@ -512,16 +563,19 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
             _TUNE_CACHE[key] = best
             timed += 1
         d.tile = best
+    if timed:
+        save_tune_cache()
     return timed
-
-
-_WGRAD_CACHE = {}
 
 
 def autotune_wgrad(ops, iters: int = 3) -> int:
     """plan-time choice between the two weight-gradient kernels (csrc/wgrad.hip: register-staged small tile / wide LDS-DMA tile)
     per problem signature: both are timed on the op's own buffers (scratch at this point; the gradient it writes is zeroed before
-    the first real run) and the winner goes into bits 8-9 of `desc.accumulate`.  Returns the number of problems timed."""
+    the first real run) and the winner goes into bits 8-9 of `desc.accumulate`.  Returns the number of problems timed.
+    The two forms split the pixel range differently, i.e. sum in a different order: like the igemm tile choice this makes the last
+    bits of a gradient depend on what a process measured -- MVLDM_TRAIN_AUTOTUNE=0 (rules only), a shared MVLDM_TUNE_CACHE file or
+    `broadcast_tune_cache` give run-to-run / rank-to-rank identical gradients.  (A form the library refuses leaves its message in
+    `mvldm_last_error()`; it is only ever read after a failing call, which overwrites it.)"""
     lib = L.load()
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -533,14 +587,17 @@ def autotune_wgrad(ops, iters: int = 3) -> int:
         d = op.u.wgrad
         if d.act_dtype == L.F32 or (d.accumulate >> 8) & 3:
             continue
-        key = (d.c0, d.c1, d.n_img, d.h_in, d.w_in, d.h_out, d.w_out, d.ksize, d.stride, d.pad, d.upsample, d.n_out, d.dy_ld, d.act_dtype)
+        key = (d.c0, d.c1, d.n_img, d.h_in, d.w_in, d.h_out, d.w_out, d.ksize, d.stride, d.pad, d.upsample, d.n_out, d.dy_ld, d.act_dtype,
+               int(d.workspace_bytes))          # (the workspace bounds the split count, hence which form wins)
         best = _WGRAD_CACHE.get(key)
         if best is None:
             trial = L.Op()
             C.memmove(C.byref(trial), C.byref(op), C.sizeof(L.Op))
             need = d.n_out * d.c_in * d.ksize * d.ksize
             if scratch is None or scratch.numel() < need:
-                scratch = torch.empty(need, dtype=torch.float32, device=torch.cuda.current_device())
+                scratch = torch.zeros(need, dtype=torch.float32, device=torch.cuda.current_device())
+            else:
+                scratch[:need].zero_()       # the trials accumulate: no Inf / NaN left over from an earlier, larger problem
             trial.u.wgrad.grad = scratch.data_ptr()
             results = []
             for form in (1, 2):
@@ -557,6 +614,8 @@ def autotune_wgrad(ops, iters: int = 3) -> int:
             _WGRAD_CACHE[key] = best
             timed += 1
         d.accumulate = (d.accumulate & 1) | (best << 8)
+    if timed:
+        save_tune_cache()
     return timed
 
 

@@ -75,6 +75,15 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
+    def wait_readers(self):
+        """call before WRITING `flat` in place on the current stream: a weight re-pack launched ahead on the trainer's side stream
+        (`MVLDMTrainer._repack_ahead`) may still be READING it.  The optimizer step, `EMAWeights.applied` (entry and exit) and the
+        checkpoint loaders go through here; without it the ~5 ms packing launch could pick up a mix of live and averaged / updated
+        weights, and because the plan is already marked current the bad packs would never be redone."""
+        ev = self.__dict__.get("_read_event")
+        if ev is not None and torch.cuda.is_available():
+            torch.cuda.current_stream().wait_event(ev)
+
     def bump(self):
         """in-place kernel updates do not move torch's version counters: recorded INFERENCE plans / packs of THIS module key
         on its own epoch instead (a frozen VAE next to it keeps its plans: modules.bump_weights_epoch(module))"""
@@ -862,6 +871,7 @@ class DistributedOptimizer:
     def step(self):
         """clip (global norm over ALL ranks' slices) + AdamW on the owned slices + all-gather of the weights"""
         self.wait()
+        self.flat.wait_readers()          # a re-pack running ahead on the side stream reads the parameters this step overwrites
         g, p = self.flat.grad, self.flat.flat
         own_sq = torch.zeros(1, dtype=torch.float32, device=g.device)
         for oa, ob in self.owned:
@@ -989,12 +999,14 @@ class EMAWeights:
     def applied(self):
         """`model = self.ema` (use_ema_sampling, diffusion_wrapper.py:460-463): the averaged weights in place of the live ones
         for the duration of the block (recorded inference plans re-pack on entry and on exit)"""
+        self.flat.wait_readers()          # (typically called right after a training window: its re-pack may still be running ahead)
         live = self.flat.flat.clone()
         self.flat.flat.copy_(self.avg)
         self.flat.bump()
         try:
             yield self.flat.module
         finally:
+            self.flat.wait_readers()
             self.flat.flat.copy_(live)
             self.flat.bump()
 
@@ -1014,7 +1026,8 @@ class MVLDMTrainer:
         self.flat = _flat_padded(denoiser, world)
         self.opt = DistributedOptimizer(self.flat, optimizer_cfg, world, rank, group, bucket_bytes, self.cfg.gradient_clip_val,
                                         collective=collective, effective_batch_size=effective_batch_size)
-        self.plans: Dict[tuple, TrainPlan] = {}
+        self.plans: Dict[tuple, TrainPlan] = {}          # insertion order = least recently used first (plan_for_parts)
+        self.max_plans = max(1, int(os.environ.get("MVLDM_TRAIN_MAX_PLANS", "4")))
         self.micro = 0
         self.global_step = 0
         self._weights_gen = 0          # bumped by every optimizer step; a TrainPlan re-packs lazily when it is about to run
@@ -1031,7 +1044,20 @@ class MVLDMTrainer:
         parts = [tuple(int(q) for q in part) for part in parts]
         key = parts[0] + (hl, wl) if len(parts) == 1 else (tuple(parts), hl, wl)
         tp = self.plans.get(key)
+        if tp is not None:
+            self.plans[key] = self.plans.pop(key)           # most recently used last
         if tp is None:
+            # The reference draws the context count and the CFG drop per micro-batch (diffusion_wrapper.py:336,381), so a window of
+            # `acc` micro-batches has S^acc shape combinations, and every recorded plan keeps its own activation arena and its own
+            # forward + transposed packs of the 926 M parameters.  Keep the `max_plans` most recently used (MVLDM_TRAIN_MAX_PLANS,
+            # default 4 -- a handful of GB each at configs[3] size); an evicted shape is recorded again when it comes back.
+            while len(self.plans) >= self.max_plans:
+                old_key = next(iter(self.plans))
+                old = self.plans.pop(old_key)
+                ev = old.__dict__.pop("_repack_event", None)
+                if ev is not None and torch.cuda.is_available():
+                    torch.cuda.current_stream().wait_event(ev)      # its re-pack may still be in flight on the side stream
+                del old
             acc = self.cfg.accumulate_grad_batches
             use_graph = self.graph and not self.opt.collective
             saved = self.flat.grad.clone() if use_graph else None       # a plan recorded mid-accumulation must not disturb it
@@ -1158,6 +1184,7 @@ class MVLDMTrainer:
         with torch.cuda.stream(side):
             tp.refresh_weights()
             tp._repack_event = side.record_event()
+        self.flat._read_event = tp._repack_event     # every in-place writer of the flat parameters waits for it (FlatParams.wait_readers)
         tp.weights_gen = self._weights_gen
 
     def training_step(self, batch, **choices) -> torch.Tensor:

@@ -261,3 +261,88 @@ def test_recorded_gradient_writes_cover_every_trained_parameter_exactly():
     tb.ops.append(None)
     tb._pgrad(m.n.bias)
     assert tb.grad_writes[-1] == (6, flat.offset[id(m.n.bias)], 8)
+
+
+def _bench(args, env_extra, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_when_started_without_a_launcher():
+    """`python bench.py --gpus 2` as a plain process (the form the driver uses for N = 1) must become a 2-rank job, not a mislabelled
+    1-GPU run: it starts torch.distributed.run itself (before touching the GPU), forwards the single JSON line of rank 0 and the
+    exit code.  MVLDM_BENCH_DRYRUN=1 stops each rank after the rendezvous + barrier (gloo), so the contract is testable without a GPU."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"MVLDM_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["dryrun"] is True
+
+
+def test_bench_refuses_a_rank_count_that_is_not_the_one_asked_for():
+    """WORLD_SIZE=1 in the environment but --gpus 2 (a launcher that started the wrong number of ranks): no line, non-zero exit"""
+    r = _bench(["--gpus", "2"], {"MVLDM_BENCH_DRYRUN": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """a rank that dies (here: no GPU in the test container, no dry-run knob) makes the launcher exit non-zero -- no silent success"""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {})
+    assert r.returncode != 0
+
+
+def _tune_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mv_ldm_amd import plan as P
+    P._TUNE_CACHE.clear(); P._WGRAD_CACHE.clear()
+    # every rank "measured" something different; rank 0's choices must win everywhere
+    P._TUNE_CACHE[(64, 32, 32, 32, 32, 320, 0, 1, 1, 0, 0, 960, 960, 320, 0, 1, 1, 1, 0, False, False, True, 1, 0)] = 13 if rank == 0 else 10
+    if rank == 1:
+        P._TUNE_CACHE[(1, 2, 3)] = 7
+    P._WGRAD_CACHE[(320, 0, 32)] = 2 - rank
+    P.broadcast_tune_cache(dist, src=0)
+    q.put((rank, dict(P._TUNE_CACHE), dict(P._WGRAD_CACHE)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_choices_are_rank_zeros_on_every_rank_and_survive_a_file(tmp_path):
+    """plan-time tile selection times candidates per process: the ranks of one job take rank 0's choices (`broadcast_tune_cache`),
+    and MVLDM_TUNE_CACHE=<file> carries them to another process (a profiler pass then records its plans without one trial launch)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tune_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2]
+    assert 13 in got[1][1].values() and (1, 2, 3) not in got[1][1] and list(got[1][2].values()) == [2]
+    from mv_ldm_amd import plan as P
+    keep = (dict(P._TUNE_CACHE), dict(P._WGRAD_CACHE))
+    try:
+        P._TUNE_CACHE.clear(); P._WGRAD_CACHE.clear()
+        key = (64, 32, 32, 32, 32, 320, 0, 1, 1, 0, 0, 960, 960, 320, 0, 1, 1, 1, 0, False, False, True, 1, 0)
+        P._TUNE_CACHE[key] = 13
+        P._WGRAD_CACHE[(320, 0, 32)] = 2
+        f = str(tmp_path / "tune.json")
+        assert P.save_tune_cache(f) == f
+        P._TUNE_CACHE.clear(); P._WGRAD_CACHE.clear()
+        assert P.load_tune_cache(f) == 2 and P._TUNE_CACHE == {key: 13} and P._WGRAD_CACHE == {(320, 0, 32): 2}
+        assert all(type(a) is type(b) for a, b in zip(next(iter(P._TUNE_CACHE)), key))       # bools stay bools: the lookup key is the tuple
+    finally:
+        P._TUNE_CACHE.clear(); P._WGRAD_CACHE.clear()
+        P._TUNE_CACHE.update(keep[0]); P._WGRAD_CACHE.update(keep[1])

@@ -18,7 +18,7 @@ import os
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record_err, rel_err
 from seeded import random_cameras, seeded_state
 
 pytestmark = pytest.mark.gpu
@@ -101,7 +101,7 @@ def test_fused_cfg_step_at_headline_shape_vs_oracle(models, oracle_steps, dtype,
         got = pipe._read_state(st, 1, v_t)
     torch.cuda.synchronize()
     assert int(st["step_ptr"].item()) == 2
-    e = rel_err(got.cpu(), oracle_steps[case])
+    e = record_err(f"headline_step/{str(dtype)[6:]}", rel_err(got.cpu(), oracle_steps[case]))
     print(f"headline step [{case}, {dtype}]: rel-err {e:.3e} (tol {STEP_TOL[dtype]})")
     assert e < STEP_TOL[dtype], (case, dtype, e)
     pipe._plans.clear()
@@ -161,7 +161,7 @@ def test_rule_based_tiles_match_the_tuned_plan(models, monkeypatch, dtype):
     assert all(t == 0 for t in tiles["0"])                          # rules only
     if dtype != torch.float32:
         assert any(t != 0 for t in tiles["1"]) or not P._TUNE_CACHE  # the tuned plan froze at least one tile (f32 is never tuned)
-    e = rel_err(outs["1"], outs["0"])
+    e = record_err(f"tuned_vs_rules/{str(dtype)[6:]}", rel_err(outs["1"], outs["0"]))
     print(f"tuned vs rule-based plan [{dtype}]: rel-err {e:.3e}; frozen tiles {sorted(set(tiles['1']))}")
     assert torch.isfinite(outs["0"]).all() and e < (1e-5 if dtype == torch.float32 else 1e-2), e
 
@@ -190,7 +190,7 @@ def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
         n_ops[mode] = sum("cfg_share" in n for n in names)
         pipe._plans.clear()
     assert n_ops == {"1": 6, "1a": 3, "0": 0}, n_ops      # conv_in + the two level-0 skips are gathered, nothing else is copied
-    e = max(rel_err(outs["1"], outs["0"]), rel_err(outs["1a"], outs["0"]))
+    e = record_err(f"cfg_share_vs_full_walk/{str(dtype)[6:]}", max(rel_err(outs["1"], outs["0"]), rel_err(outs["1a"], outs["0"])))
     print(f"shared CFG prefix vs full walk [{dtype}], two DDIM steps: rel-err {e:.3e}")
     # (bf16: the prefix GEMMs see 10 instead of 18 images, the rules pick other tiles, sums round differently: two bf16 evaluations
     #  of one forward differ by about as much as each differs from f32, ~2e-2 in eps = ~2.5e-3 in x per step; measured 5.2e-3)
@@ -219,7 +219,7 @@ def test_tail_drop_equals_the_full_walk(models, monkeypatch, dtype):
         n_ops[mode] = sum("keep_views" in mm.name or "eps.scatter" in mm.name for mm in st["plan"].meta)
         pipe._plans.clear()
     assert n_ops == {"1": 3, "0": 0}, n_ops
-    e = rel_err(outs["1"], outs["0"])
+    e = record_err(f"tail_drop_vs_full_walk/{str(dtype)[6:]}", rel_err(outs["1"], outs["0"]))
     print(f"tail drop vs full walk [{dtype}], two DDIM steps: rel-err {e:.3e}")
     assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 1.5e-2), e
 

@@ -12,13 +12,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import record_err, rel_err
 from seeded import load_seeded, random_cameras
 
 pytestmark = pytest.mark.gpu
 
 TOL_BLOCK = {torch.float32: 2e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}
 TOL_MODEL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}
+TOL_G11 = {torch.float32: 1e-3, torch.float16: 1.6e-2, torch.bfloat16: 1e-1}      # whole samples incl. both VAE passes (G5 uses 2 x TOL_MODEL)
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 IDS = ["f32", "bf16", "f16"]
 GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
@@ -59,7 +60,7 @@ def test_spatial_transformer_3d_vs_reference_golden(M, golden, dtype):
         with M.compute_dtype(dtype):
             y = m(torch.from_numpy(g[f"c{i}_x"]).cuda())
         assert y.shape == g[f"c{i}_y"].shape
-        e = rel_err(y.float().cpu(), g[f"c{i}_y"])
+        e = record_err(f"g1_block/{str(dtype)[6:]}", rel_err(y.float().cpu(), g[f"c{i}_y"]))
         assert e < TOL_BLOCK[dtype], (i, e)
 
 
@@ -85,6 +86,7 @@ def test_mvunet_forward_vs_reference_golden(M, golden, dtype):
             y = m(x, t)
             yw = m.forward_walk(x, t)
         e, ew = rel_err(y.cpu(), g[f"c{i}_y"]), rel_err(yw.cpu(), g[f"c{i}_y"])
+        record_err(f"g4_model/{str(dtype)[6:]}", max(e, ew))
         assert e < TOL_MODEL[dtype] and ew < TOL_MODEL[dtype], (i, topo, e, ew)
         ran += 1
     assert ran >= 3
@@ -131,6 +133,17 @@ def test_parallel_lanes_give_the_serial_result(M, monkeypatch):
         outs[rows] = y
         kinds = [mm.kind for mm in eager.meta]
         assert (L.OP_PAR_BEGIN in kinds) == (rows != "0")
+        if rows != "0":
+            # a range cut INSIDE a group is refused before anything is launched (it used to be noticed after the lanes
+            # had been enqueued on side streams, with no join recorded)
+            i0 = kinds.index(L.OP_PAR_BEGIN)
+            i1 = kinds.index(L.OP_PAR_END, i0)
+            before = m.compile(2, 3, 16, 16)["out"].clone()
+            for first, last in ((0, i0 + 1), (i0 + 1, len(kinds)), (i0 + 1, i1)):
+                with pytest.raises(L.MvldmError, match="parallel group"):
+                    eager.run(first, last)
+            torch.cuda.synchronize()
+            assert torch.equal(m.compile(2, 3, 16, 16)["out"], before)      # nothing ran
     assert torch.equal(outs["0"], outs["16384"])
 
 
@@ -180,6 +193,42 @@ def test_step_and_sample_vs_reference_golden(M, golden, dtype):
             e_step = rel_err(x_prev.cpu(), g[p + "step_x_prev"])
         assert e_step < TOL_MODEL[dtype], (ci, "step", e_step)
         assert e_img < 2 * TOL_MODEL[dtype], (ci, "sample", e_img)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_configs0_and_configs4_shapes_vs_reference_golden(M, golden, dtype):
+    """G11 = the reference's own DiffusionWrapper.sample at the geometry of BASELINE.json configs[0] (1 ctx + 1 tgt view, 64x64 images,
+    8x8 latents, 5 DDIM steps: the literal CPU-reference case) and of configs[4] (1 + 8 = 9 views, 64x64 LATENTS, above the
+    `h <= 32` gate of mvunet.py:137,190, so the level-0 multi-view blocks are skipped and the deeper 3-D attentions see 9 views),
+    reduced width, through the fused sampler AND the literal loop (`sample_literal`)"""
+    from mv_ldm_amd.mvunet import MultiViewUNet
+    from mv_ldm_amd.pipeline import MVLDMPipeline, SamplerCfg
+    from mv_ldm_amd.scheduler import DDIMScheduler
+    from mv_ldm_amd.vae import AutoencoderKL
+    g = golden("g11_configs")
+    widths = [int(v) for v in g["widths"]]
+    for ci in range(int(g["n"])):
+        p = f"c{ci}_"
+        n_steps = int(g[p + "n_steps"])
+        with M.compute_dtype(dtype):
+            den = MultiViewUNet(sd_cfg(M, widths), 11, 4)
+            vae = AutoencoderKL.from_pretrained("x", config_overrides=dict(block_out_channels=tuple(int(v) for v in g[p + "vae_widths"]), layers_per_block=1))
+            assert abs(load_seeded(den, 400) - float(g[p + "checksum_denoiser"])) < 1e-6
+            assert abs(load_seeded(vae, 401) - float(g[p + "checksum_vae"])) < 1e-6
+            pipe = MVLDMPipeline(den.cuda(), vae.cuda(), DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, n_steps))
+            pipe.set_timesteps(n_steps)
+            extr, intr = torch.from_numpy(g[p + "extr"]), torch.from_numpy(g[p + "intr"])
+            v_c = g[p + "ctx_img"].shape[1]
+            batch = {"context": {"image": torch.from_numpy(g[p + "ctx_img"]), "extrinsics": extr[:, :v_c], "intrinsics": intr[:, :v_c]},
+                     "target": {"extrinsics": extr[:, v_c:], "intrinsics": intr[:, v_c:]}}
+            kw = dict(x_T=torch.from_numpy(g[p + "x_T"]), encode_noise=torch.from_numpy(g[p + "enc_noise"]))
+            img, _ = pipe.sample(batch, **kw)
+            img_l, _ = pipe.sample_literal(batch, **kw)
+        want = torch.from_numpy(g[p + "img"].astype("float32"))
+        e, el = rel_err(img.cpu(), want), rel_err(img_l.cpu(), want)
+        record_err(f"g11_c{ci}/{str(dtype)[6:]}", max(e, el))
+        # (f32: the fixture's own f16 storage is 2.4e-4 absolute on [0, 1]; 16-bit: 2 x the measured maximum, tests/golden/measured_errors_r04.json)
+        assert max(e, el) < TOL_G11[dtype], (ci, e, el)
 
 
 def test_ddpm_ancestral_sampling_vs_oracle(M):

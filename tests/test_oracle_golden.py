@@ -102,3 +102,28 @@ def test_g5_step_and_sample(golden):
         x_prev = PL.step(den, sch, x_t, torch.tensor(int(g[p + "step_ts"])), ctx_in, rays,
                          torch.ones_like(x_t[:, :, :1]), use_cfg=use_cfg)
         assert rel_err(x_prev, g[p + "step_x_prev"]) < 2e-5
+
+
+def test_g11_configs0_and_configs4_shapes(golden):
+    """G11 (tests/golden/make_golden_configs.py, the reference's own DiffusionWrapper.sample): BASELINE.json configs[0] literally
+    (1 ctx + 1 tgt view, 64x64 -> 8x8 latents, 5 DDIM steps) and configs[4]'s geometry (9 views, 64x64 latents: above the `h <= 32`
+    gate of mvunet.py:137,190) -- pins the oracle's walk at both ends of the resolution gate"""
+    g = golden("g11_configs")
+    widths = [int(v) for v in g["widths"]]
+    for ci in range(int(g["n"])):
+        p = f"c{ci}_"
+        den = _oracle_mvunet("sd", widths)
+        vae = AutoencoderKL.from_pretrained("x", config_overrides=dict(block_out_channels=tuple(int(v) for v in g[p + "vae_widths"]),
+                                                                       layers_per_block=1)).eval()
+        assert abs(load_seeded(den, 400) - float(g[p + "checksum_denoiser"])) < 1e-6
+        assert abs(load_seeded(vae, 401) - float(g[p + "checksum_vae"])) < 1e-6
+        sch = DDIMScheduler(clip_sample=False)
+        sch.set_timesteps(int(g[p + "n_steps"]))
+        extr, intr = torch.from_numpy(g[p + "extr"]), torch.from_numpy(g[p + "intr"])
+        v_c = g[p + "ctx_img"].shape[1]
+        img, _ = PL.sample(den, vae, sch, torch.from_numpy(g[p + "ctx_img"]), extr[:, :v_c], intr[:, :v_c], extr[:, v_c:], intr[:, v_c:],
+                           x_T=torch.from_numpy(g[p + "x_T"]), encode_noise=torch.from_numpy(g[p + "enc_noise"]), use_cfg=True)
+        want = torch.from_numpy(g[p + "img"].astype("float32"))
+        assert img.shape == want.shape
+        assert float((img - want).abs().max()) < 1e-3, ci          # (the fixture stores the image in f16: 2^-11 absolute on [0, 1])
+        assert rel_err(img, want) < 6e-4, ci
