@@ -24,7 +24,8 @@ from seeded import random_cameras, seeded_state
 pytestmark = pytest.mark.gpu
 GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
 
-STEP_TOL = {torch.float32: 1e-3, torch.float16: 1e-2, torch.bfloat16: 3e-2}
+# f32: the north-star tolerance (measured 9e-7); 16-bit: 2 x the maximum measured on MI355X (tests/golden/measured_errors_r04.json: 3.9e-4 / 3.1e-3)
+STEP_TOL = {torch.float32: 1e-3, torch.float16: 8e-4, torch.bfloat16: 6.5e-3}
 # 50 DDIM steps, CFG 3.0, random-init weights: the end-to-end drift of the 16-bit paths against the f32 HIP path.
 DRIFT_TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}      # measured on MI355X: 7.2e-4 / 5.8e-3 (profiles/r02_drift.json)
 CASES = {"ctx1_tgt4": (1, 4), "ctx2_tgt3": (2, 3)}
@@ -179,6 +180,10 @@ def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
     for mode in ("1", "1a", "0"):          # 1: targets once per step + context once per sample; 1a: conditional images once per step; 0: all
         monkeypatch.setenv("MVLDM_CFG_SHARE", mode)
         monkeypatch.setenv("MVLDM_AUTOTUNE", "0")
+        # ONE tile for every implicit GEMM of all three plans: the shared layers see 10 (or 8) images instead of 18, the size rules would
+        # pick other tiles and the K sums would round differently (5.2e-3 in bf16 with the rules); with the tile pinned a row's dot
+        # product is the same instruction sequence whatever the row count, and what is left is the merged attention of the first block
+        monkeypatch.setenv("MVLDM_IGEMM_TILE", "2")
         pipe = _pipe(m)
         with M.compute_dtype(dtype):
             st = pipe._compile(b, v_c, v_t, 32, 32, dtype, 50)
@@ -192,9 +197,7 @@ def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
     assert n_ops == {"1": 6, "1a": 3, "0": 0}, n_ops      # conv_in + the two level-0 skips are gathered, nothing else is copied
     e = record_err(f"cfg_share_vs_full_walk/{str(dtype)[6:]}", max(rel_err(outs["1"], outs["0"]), rel_err(outs["1a"], outs["0"])))
     print(f"shared CFG prefix vs full walk [{dtype}], two DDIM steps: rel-err {e:.3e}")
-    # (bf16: the prefix GEMMs see 10 instead of 18 images, the rules pick other tiles, sums round differently: two bf16 evaluations
-    #  of one forward differ by about as much as each differs from f32, ~2e-2 in eps = ~2.5e-3 in x per step; measured 5.2e-3)
-    assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 1.5e-2), e
+    assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 2e-3), e
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -221,7 +224,8 @@ def test_tail_drop_equals_the_full_walk(models, monkeypatch, dtype):
     assert n_ops == {"1": 3, "0": 0}, n_ops
     e = record_err(f"tail_drop_vs_full_walk/{str(dtype)[6:]}", rel_err(outs["1"], outs["0"]))
     print(f"tail drop vs full walk [{dtype}], two DDIM steps: rel-err {e:.3e}")
-    assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 1.5e-2), e
+    # (rules only, same row counts in front of the drop: measured 0.0 in both dtypes)
+    assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 1e-4), e
 
 
 def test_plans_follow_weight_changes(models):

@@ -17,9 +17,12 @@ from seeded import load_seeded, random_cameras
 
 pytestmark = pytest.mark.gpu
 
-TOL_BLOCK = {torch.float32: 2e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}
-TOL_MODEL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}
-TOL_G11 = {torch.float32: 1e-3, torch.float16: 1.6e-2, torch.bfloat16: 1e-1}      # whole samples incl. both VAE passes (G5 uses 2 x TOL_MODEL)
+# 16-bit tolerances = 2 x the maximum measured on MI355X (tests/golden/measured_errors_r04.json, written by MVLDM_TEST_REPORT: g1_block,
+# g4_model, g11_*), f32 = the north-star 1e-3 or tighter: a 1 % regression of a 16-bit kernel fails these, the round numbers of rounds 1-3 did not
+TOL_BLOCK = {torch.float32: 2e-4, torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}      # G1: measured 5.8e-7 / 7.2e-4 / 5.8e-3
+TOL_G4 = {torch.float32: 1e-3, torch.float16: 3.7e-3, torch.bfloat16: 2.9e-2}         # G4: measured 1.6e-6 / 1.8e-3 / 1.4e-2
+TOL_MODEL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}          # G5 step / sample (x 2): not re-measured this round
+TOL_G11 = {torch.float32: 5e-4, torch.float16: 2.3e-3, torch.bfloat16: 2.2e-2}        # whole samples; measured 1.8e-4 (the fixture's f16 storage) / 1.1e-3 / 1.06e-2
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 IDS = ["f32", "bf16", "f16"]
 GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
@@ -87,7 +90,7 @@ def test_mvunet_forward_vs_reference_golden(M, golden, dtype):
             yw = m.forward_walk(x, t)
         e, ew = rel_err(y.cpu(), g[f"c{i}_y"]), rel_err(yw.cpu(), g[f"c{i}_y"])
         record_err(f"g4_model/{str(dtype)[6:]}", max(e, ew))
-        assert e < TOL_MODEL[dtype] and ew < TOL_MODEL[dtype], (i, topo, e, ew)
+        assert e < TOL_G4[dtype] and ew < TOL_G4[dtype], (i, topo, e, ew)
         ran += 1
     assert ran >= 3
 
@@ -191,6 +194,8 @@ def test_step_and_sample_vs_reference_golden(M, golden, dtype):
             x_prev = pipe.step(pipe.denoiser, x_t, torch.tensor(int(g[p + "step_ts"])), ctx_in, rays,
                                torch.ones_like(x_t[:, :, :1]))
             e_step = rel_err(x_prev.cpu(), g[p + "step_x_prev"])
+        record_err(f"g5_step/{str(dtype)[6:]}", e_step)
+        record_err(f"g5_sample_img/{str(dtype)[6:]}", e_img)
         assert e_step < TOL_MODEL[dtype], (ci, "step", e_step)
         assert e_img < 2 * TOL_MODEL[dtype], (ci, "sample", e_img)
 

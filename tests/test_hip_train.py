@@ -3,8 +3,9 @@
 gradient accumulation against the oracle's restated recipe (oracle/train.py: clip 0.1, AdamW, LinearLR).
 
 Tolerances: f32 path -- loss 1e-4, every parameter-gradient norm 2e-3, sampled gradient entries 2e-3 (relative L2);
-bf16 path (activations and activation gradients in bf16, fp32 weight gradients) -- loss 2e-2, gradient norms 1.5e-1
-(the small deep-layer gradients are sums of bf16-rounded products), global gradient norm 5e-2."""
+bf16 path (activations and activation gradients in bf16, fp32 weight gradients) -- 2 x the maxima measured on MI355X
+(tests/golden/measured_errors_r04.json): loss 1.3e-3 (6.1e-4), worst parameter-gradient norm 3e-2 (1.4e-2), global gradient norm
+8e-3 (3.6e-3), sampled gradient entries 5.5e-2 (2.6e-2)."""
 import numpy as np
 import pytest
 import torch
@@ -54,7 +55,7 @@ def test_training_step_vs_reference_golden(golden, dtype):
         loss = float(tr.training_step(batch, **hip_choices(ch)))
         torch.cuda.synchronize()
         record_err(f"g9_loss/{str(dtype)[6:]}", abs(loss - float(g[p + "loss"])) / float(g[p + "loss"]))
-        assert abs(loss - float(g[p + "loss"])) < (1e-4 if f32 else 2e-2) * float(g[p + "loss"]), (ci, loss, float(g[p + "loss"]))
+        assert abs(loss - float(g[p + "loss"])) < (1e-4 if f32 else 1.3e-3) * float(g[p + "loss"]), (ci, loss, float(g[p + "loss"]))
         want = dict(zip(names, g[p + "grad_norms"]))
         in_flat = {id(q) for q in tr.flat.params}
         worst, tot_got, tot_ref = 0.0, 0.0, 0.0
@@ -71,15 +72,15 @@ def test_training_step_vs_reference_golden(golden, dtype):
                 worst = max(worst, abs(gn - want[n]) / want[n])
         record_err(f"g9_worst_param_grad_norm/{str(dtype)[6:]}", worst)
         record_err(f"g9_global_grad_norm/{str(dtype)[6:]}", abs(tot_got ** 0.5 - tot_ref ** 0.5) / tot_ref ** 0.5)
-        assert worst < (2e-3 if f32 else 1.5e-1), (ci, worst)
-        assert abs(tot_got ** 0.5 - tot_ref ** 0.5) < (1e-3 if f32 else 5e-2) * tot_ref ** 0.5
+        assert worst < (2e-3 if f32 else 3e-2), (ci, worst)
+        assert abs(tot_got ** 0.5 - tot_ref ** 0.5) < (1e-3 if f32 else 8e-3) * tot_ref ** 0.5
         for k in g.files:
             if k.startswith(p + "grad/"):
                 got = 2.0 * own[k[len(p) + 5:]].grad.reshape(-1).float().cpu()
                 got = got[::max(1, got.numel() // 2048)][:2048]
                 ref = torch.from_numpy(g[k])
                 e = record_err(f"g9_sampled_grad/{str(dtype)[6:]}", float((got - ref).norm() / ref.norm().clamp_min(1e-30)))
-                assert e < (2e-3 if f32 else 1.5e-1), (k, e)
+                assert e < (2e-3 if f32 else 5.5e-2), (k, e)
 
 
 def test_accumulation_clipping_adamw_step_vs_oracle(golden):
