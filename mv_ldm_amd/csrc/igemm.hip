@@ -1603,6 +1603,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
 // tile 12: the persistent, epilogue-pipelined Linear kernel of linear_pp.hip; tile 13: the persistent wide Linear of linear_pw.hip
 int linear_pp_run(const mvldm_igemm_desc& d, hipStream_t s);
 int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s);
+int linear_ws_run(const mvldm_igemm_desc& d, hipStream_t s);      // tile 14: weight-stationary Linear for K = 320 (linear_ws.hip)
 
 int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
     IgemmParams p;
@@ -1615,6 +1616,10 @@ int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
     if ((d.tile & 15) == 13) {
         MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
         return linear_pw_run(d, s);
+    }
+    if ((d.tile & 15) == 14) {
+        MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
+        return linear_ws_run(d, s);
     }
     int rc = fill_params(d, p, tile);
     if (rc) return rc;

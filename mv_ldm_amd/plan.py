@@ -468,7 +468,7 @@ class Builder:
 # MVLDM_TUNE_TILES=0,2,9,... restricts the candidates (the small 64x64 / 32x64 tiles only ever win below ~4 scenes: +2 % at b = 1).
 _TUNE_CACHE = {}
 _WGRAD_CACHE = {}
-_TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) if os.environ.get("MVLDM_TUNE_TILES") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)
+_TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) if os.environ.get("MVLDM_TUNE_TILES") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)
 
 
 # ---- the tune cache as data: a file (MVLDM_TUNE_CACHE=<path>.json: read at import, rewritten whenever a plan timed new problems) and a

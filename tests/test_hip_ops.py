@@ -291,6 +291,80 @@ def test_wide_persistent_tile_two_sources(ops, dtype, n, h, c0, c1, cout):
     close(nchw(y), ref, dtype, "dual-source 1x1 tile13")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,cout", [(300, 320), (1000, 960), (70001, 320), (40000, 640), (33, 320)])
+def test_linear_weight_stationary_tile(ops, dtype, rows, cout):
+    """tile 14 (linear_ws.hip: K = 320, a wave keeps its 32 columns' weights in registers, 64-row slots stream through a 3-slot ring,
+    the epilogue of a 32-row block runs under the next block's MFMAs): ragged M (partial slots, fewer slots than workgroups), one to
+    three column slices, residual / none / no bias"""
+    cin = 320
+    x, wt = rnd((rows, cin), 71, dtype), rnd((cout, cin), 72, dtype, 1 / math.sqrt(cin))
+    b = torch.randn(cout, generator=G(73)) * 0.1
+    res = rnd((rows, cout), 74, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    lin = F.linear(x.double(), wt.double(), b.double())
+    xg = x.to(dtype).cuda()
+    y = ops.linear(xg, pw, b.cuda(), residual=res.to(dtype).cuda(), tile=14)
+    close(y.float().cpu().double(), lin + res.double(), dtype, "linear+res tile14")
+    y = ops.linear(xg, pw, None, tile=14)
+    close(y.float().cpu().double(), F.linear(x.double(), wt.double()), dtype, "linear nobias tile14")
+    y = ops.linear(xg, pw, b.cuda(), tile=14)
+    close(y.float().cpu().double(), lin, dtype, "linear tile14")
+    y0 = ops.linear(xg, pw, b.cuda(), tile=7)
+    assert (y.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
+    assert (y != y0).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows", [300, 33000])
+def test_geglu_weight_stationary_tile(ops, dtype, rows):
+    """tile 14 with GEGLU: a wave's 32 weight rows are 16 value + 16 gate columns, the exact-erf GELU runs under the next block's MFMAs"""
+    c = 320
+    x, wt = rnd((rows, c), 75, dtype), rnd((8 * c, c), 76, dtype, 1 / math.sqrt(c))
+    b = torch.randn(8 * c, generator=G(77)) * 0.1
+    pw = ops.pack_weight(wt.cuda(), dtype, geglu=True)
+    a, g = F.linear(x.double(), wt.double(), b.double()).chunk(2, -1)
+    y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=14)
+    assert y.shape == (rows, 4 * c)
+    close(y.float().cpu().double(), a * F.gelu(g), dtype, "geglu tile14")
+    y7 = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=7)
+    assert (y.float() - y7.float()).abs().max().item() <= 2e-2 * y7.float().abs().max().item()
+
+
+def test_weight_stationary_tile_race_screen_and_refusals(ops):
+    """tile 14: bit-identical results launch after launch under memory-system noise (counted vmcnt waits over ring refills, asm residual
+    loads and asm stores in one in-order queue); K != 320 / a second source / an activation epilogue are errors, not fallbacks"""
+    import mv_ldm_amd._lib as L
+    torch.manual_seed(0)
+    side, noise = torch.cuda.Stream(), torch.randn(16 << 20, device="cuda")
+    for rows, n, epi, res in ((150000, 2560, 2, False), (200001, 320, 0, True), (90000, 960, 0, False)):
+        x = torch.randn(rows, 320, device="cuda").to(torch.bfloat16)
+        pw = ops.pack_weight(torch.randn(n, 320, device="cuda") / 320 ** 0.5, torch.bfloat16, geglu=epi == 2)
+        b = torch.randn(n, device="cuda")
+        r = torch.randn(rows, n, device="cuda").to(torch.bfloat16) if res else None
+        ref = ops.linear(x, pw, b, residual=r, epilogue=epi, tile=14).clone()
+        ref7 = ops.linear(x, pw, b, residual=r, epilogue=epi, tile=7)
+        assert (ref.float() - ref7.float()).abs().max().item() <= 2e-2 * ref7.float().abs().max().item()
+        for i in range(40):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    noise.mul_(1.0001)
+            assert torch.equal(ops.linear(x, pw, b, residual=r, epilogue=epi, tile=14), ref), (rows, i)
+    # in place: x += f(x)
+    h = torch.randn(30000, 320, device="cuda").to(torch.bfloat16)
+    x = torch.randn(30000, 320, device="cuda").to(torch.bfloat16)
+    pw = ops.pack_weight(torch.randn(320, 320, device="cuda") / 320 ** 0.5, torch.bfloat16)
+    want = ops.linear(x, pw, None, residual=h, tile=7)
+    got = ops.linear(x, pw, None, residual=h, out=h, tile=14)
+    assert (got.float() - want.float()).abs().max().item() <= 2e-2 * want.float().abs().max().item()
+    torch.cuda.synchronize()
+    pw640 = ops.pack_weight(torch.randn(320, 640, device="cuda"), torch.bfloat16)
+    with pytest.raises(L.MvldmError):
+        ops.linear(torch.randn(128, 640, device="cuda").to(torch.bfloat16), pw640, tile=14)
+    with pytest.raises(L.MvldmError):
+        ops.linear(x, pw, None, epilogue=1, tile=14)
+
+
 def test_wide_persistent_tile_race_screen(ops):
     """like the tile-12 screen: the counted-vmcnt ring across tile boundaries, the rolling asm residual loads and the asm stores of
     tile 13 must give bit-identical results launch after launch while another stream keeps the memory system busy"""

@@ -14,7 +14,7 @@ for lvl, (hw, c) in enumerate([(32, 320), (16, 640), (8, 1280)]):
     rows = n * hw * hw
     SH += [(f"L{lvl}.geglu", rows, c, 8 * c, 2, False), (f"L{lvl}.ff_out", rows, 4 * c, c, 0, True),
            (f"L{lvl}.qkv", rows, c, 3 * c, 0, False), (f"L{lvl}.to_out", rows, c, c, 0, True)]
-TILES = tuple(int(t) for t in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 2, 3, 9, 10, 12, 13)
+TILES = tuple(int(t) for t in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 2, 3, 9, 10, 12, 13, 14)
 for name, rows, k, nn, epi, res in SH:
     x = torch.randn(rows, k, device="cuda").to(dtype)
     w = torch.randn(nn, k, device="cuda") / k ** 0.5
