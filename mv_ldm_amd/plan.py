@@ -27,7 +27,8 @@ from .ops import PackedWeight, dt, ptr
 
 def _PIN_TILE() -> int:
     """MVLDM_IGEMM_TILE=<n> (read per call: tests set it with monkeypatch): every 16-bit block-major conv / Linear a Builder emits
-    without an explicit tile takes tile n instead of the size rules / the plan-time tuning.  With the tile pinned a row's dot product
+    without an explicit tile takes tile n and a single K pass instead of the size rules / the plan-time tuning (the split-K count follows the
+    workgroup count, i.e. the row count, and changes the summation order like a tile does).  With both pinned a row's dot product
     is the same instruction sequence whatever the row count of the launch, so two plans that push the same rows through differently
     sized launches (the shared CFG prefix against the full walk) can be compared far below the 16-bit rounding of a re-tiled sum."""
     v = os.environ.get("MVLDM_IGEMM_TILE")
@@ -199,7 +200,7 @@ class Builder:
         d.row_bias_ld = 0 if row_bias is None else row_bias.stride(0)
         d.epilogue, d.act_dtype, d.dst_dtype = epilogue, dt(x), dt(out)
         if tile == 0 and _PIN_TILE() and x.dtype != torch.float32 and pw.k_order == 1:
-            tile = _PIN_TILE()        # (test knob MVLDM_IGEMM_TILE: one tile for every 16-bit block-major launch, see _PIN_TILE)
+            tile, splitk = _PIN_TILE(), 1        # (test knob MVLDM_IGEMM_TILE: one tile, one K pass for every 16-bit block-major launch, see _PIN_TILE)
         d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
         d.dst_ld = out.shape[-1] if out.shape[-1] != n_dst else 0
         d.k_order = pw.k_order

@@ -177,12 +177,15 @@ def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
     v_c, v_t, b = 1, 4, 2
     ctx_lat, x_t, extr, intr = _inputs(v_c, v_t, b=b, seed=13)
     outs, n_ops = {}, {}
-    for mode in ("1", "1a", "0"):          # 1: targets once per step + context once per sample; 1a: conditional images once per step; 0: all
-        monkeypatch.setenv("MVLDM_CFG_SHARE", mode)
+    # 1: targets once per step + context once per sample; 1a: conditional images once per step; 0: all.  "+m": with the first multi-view
+    # block's shared attention scores (the default), else MVLDM_CFG_SHARE_ATTN=0
+    for mode in ("1+m", "1", "1a", "0"):
+        monkeypatch.setenv("MVLDM_CFG_SHARE", mode.rstrip("+m"))
+        monkeypatch.setenv("MVLDM_CFG_SHARE_ATTN", "1" if mode.endswith("+m") else "0")
         monkeypatch.setenv("MVLDM_AUTOTUNE", "0")
-        # ONE tile for every implicit GEMM of all three plans: the shared layers see 10 (or 8) images instead of 18, the size rules would
-        # pick other tiles and the K sums would round differently (5.2e-3 in bf16 with the rules); with the tile pinned a row's dot
-        # product is the same instruction sequence whatever the row count, and what is left is the merged attention of the first block
+        # ONE tile and ONE K pass for every implicit GEMM of all plans: the shared layers see 10 (or 8) images instead of 18, the size
+        # rules would pick other tiles / split counts and the K sums would round differently; pinned, a row's dot product is the same
+        # instruction sequence whatever the row count
         monkeypatch.setenv("MVLDM_IGEMM_TILE", "2")
         pipe = _pipe(m)
         with M.compute_dtype(dtype):
@@ -194,10 +197,16 @@ def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
         names = [mm.name for mm in st["plan"].meta]
         n_ops[mode] = sum("cfg_share" in n for n in names)
         pipe._plans.clear()
-    assert n_ops == {"1": 6, "1a": 3, "0": 0}, n_ops      # conv_in + the two level-0 skips are gathered, nothing else is copied
-    e = record_err(f"cfg_share_vs_full_walk/{str(dtype)[6:]}", max(rel_err(outs["1"], outs["0"]), rel_err(outs["1a"], outs["0"])))
-    print(f"shared CFG prefix vs full walk [{dtype}], two DDIM steps: rel-err {e:.3e}")
-    assert all(torch.isfinite(o).all() for o in outs.values()) and e < (2e-6 if dtype == torch.float32 else 2e-3), e
+    assert n_ops == {"1+m": 6, "1": 6, "1a": 3, "0": 0}, n_ops      # conv_in + the two level-0 skips are gathered, nothing else is copied
+    e_gemm = record_err(f"cfg_share_vs_full_walk_pinned/{str(dtype)[6:]}", max(rel_err(outs["1"], outs["0"]), rel_err(outs["1a"], outs["0"])))
+    e = record_err(f"cfg_share_vs_full_walk/{str(dtype)[6:]}", rel_err(outs["1+m"], outs["0"]))
+    print(f"shared CFG prefix vs full walk [{dtype}], two DDIM steps: rel-err {e_gemm:.3e} (pinned tiles, separate attention), {e:.3e} (merged attention)")
+    # The shared LAYERS are the same arithmetic on the same values: with tile and split pinned the bf16 plans are bit-identical.
+    # The shared attention SCORES are a different evaluation order of the softmax (two partial softmaxes combined by their log-sum-exp, each
+    # partial output rounded to bf16): 2 x the measured 4.6e-3 after two DDIM steps
+    assert all(torch.isfinite(o).all() for o in outs.values())
+    assert e_gemm < (2e-6 if dtype == torch.float32 else 1e-5), e_gemm           # (bf16: measured 0.0 -- bit-identical)
+    assert e < (2e-6 if dtype == torch.float32 else 9.5e-3), e
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
