@@ -19,7 +19,7 @@ def resources():
 
 def test_report_covers_every_kernel_family(resources):
     names = " ".join(resources)
-    for fam in ("igemm_bl_kernel", "igemm_halo_kernel", "igemm_kernel", "linear_pp_kernel", "attention_kernel", "attention_bwd",
+    for fam in ("igemm_bl_kernel", "igemm_halo_kernel", "igemm_kernel", "linear_pp_kernel", "linear_pw_kernel", "linear_ws_kernel", "attention_kernel", "attention_bwd",
                 "wgrad_kernel", "gn_", "layernorm", "adamw"):
         assert fam in names, fam
     assert all("vgpr" in v and "scratch" in v for v in resources.values())
@@ -31,7 +31,7 @@ def test_hot_kernels_use_no_scratch(resources):
     registers, are no longer instantiated -- the library refuses that combination).  Forward attention is compiled to an
     occupancy target (4 / 3 / 2 waves per SIMD by head dim); since the K / V staging went to buffer descriptors (round 3) the
     kernels of the UNet's head dims (DP <= 64: d = 40, 64) are spill-free up to one register outside the loop."""
-    hot = re.compile(r"igemm_bl_kernelIDF16[b_]|igemm_halo_kernelIDF16[b_]|linear_pp_kernel|wgrad_dma_kernel|wgrad_kernelIDF16")
+    hot = re.compile(r"igemm_bl_kernelIDF16[b_]|igemm_halo_kernelIDF16[b_]|linear_pp_kernel|linear_pw_kernel|linear_ws_kernel|wgrad_dma_kernel|wgrad_kernelIDF16")
     bad = {k: (v["scratch"], v.get("vgpr_spill", 0)) for k, v in resources.items()
            if hot.search(k) and (v["scratch"] or v.get("vgpr_spill", 0))}
     assert not bad, bad
@@ -51,3 +51,7 @@ def test_register_budgets(resources):
         assert v["vgpr"] + v.get("agpr", 0) <= 512, k
         if "linear_pp_kernel" in k:
             assert v["vgpr"] <= 224 and v["waves_per_simd"] >= 2, (k, v)
+        if "linear_pw_kernel" in k:      # tile 13: 8 waves, 160 accumulators at 256 x 320 (round 4: a scratch access in its K loop would also
+            assert v["vgpr"] <= 256 and v["waves_per_simd"] >= 2, (k, v)        # break the counted vmcnt waits' assumptions about what is in flight)
+        if "linear_ws_kernel" in k:      # tile 14: eleven waves = three per SIMD: 168 registers hold 80 of weights, two accumulators, the fragment pipeline
+            assert v["vgpr"] <= 168 and v["waves_per_simd"] >= 3, (k, v)
