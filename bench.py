@@ -452,7 +452,9 @@ def main():
                                "choices, MVLDM_TUNE_CACHE=<file> carries them to another process",
                        "cache_file": os.environ.get("MVLDM_TUNE_CACHE"),
                        "problems_timed": len(P._TUNE_CACHE),
-                       "frozen_tiles": {str(t): sum(1 for v in P._TUNE_CACHE.values() if v == t) for t in sorted(set(P._TUNE_CACHE.values()))}}
+                       "frozen_tiles": (lambda ch: {str(t): sum(1 for c in ch if c[0] == t) for t in sorted({c[0] for c in ch})})(
+                           [P._unpack_choice(v) for v in P._TUNE_CACHE.values()]),
+                       "frozen_splits": sum(1 for v in P._TUNE_CACHE.values() if P._unpack_choice(v)[1] is not None)}
 
     def two_roof(meta, ms):
         """sum over the plan's ops of max(flops / MFMA peak, bytes / HBM peak) against the measured sum"""

@@ -477,7 +477,7 @@ _TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) i
 # explain -- can freeze different tiles (different last-bit rounding, and rocprof tables full of trial launches).  With the file a
 # second process records its plans WITHOUT a single trial launch; `broadcast_tune_cache` gives the ranks of a job rank 0's choices.
 def tune_cache_state() -> dict:
-    return {"version": 1, "igemm": {json.dumps(list(k)): int(v) for k, v in _TUNE_CACHE.items()},
+    return {"version": 2, "igemm": {json.dumps(list(k)): (int(v) if isinstance(v, int) else list(v)) for k, v in _TUNE_CACHE.items()},
             "wgrad": {json.dumps(list(k)): int(v) for k, v in _WGRAD_CACHE.items()}}
 
 
@@ -487,7 +487,7 @@ def set_tune_cache_state(state: dict, replace: bool = False) -> None:
         _WGRAD_CACHE.clear()
     for name, cache in (("igemm", _TUNE_CACHE), ("wgrad", _WGRAD_CACHE)):
         for k, v in (state.get(name) or {}).items():
-            cache[tuple(json.loads(k))] = int(v)
+            cache[tuple(json.loads(k))] = int(v) if isinstance(v, int) else list(v)
 
 
 def save_tune_cache(path: Optional[str] = None) -> Optional[str]:
@@ -527,11 +527,23 @@ def _igemm_signature(d) -> tuple:
             bool(d.bias), d.splitk, d.workspace_bytes)
 
 
+_SMALL_ROWS = int(os.environ.get("MVLDM_TUNE_SMALL_ROWS", "64"))       # launches below this many output rows keep the rules
+_SPLITS = (0, 1, 2, 4, 8, 16, 32)
+
+
+def _unpack_choice(v):
+    """a cache entry is the tile (int: files of earlier rounds) or [tile, splitk]; splitk None = leave the descriptor's"""
+    return (int(v), None) if isinstance(v, int) else (int(v[0]), None if v[1] is None else int(v[1]))
+
+
 def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
     """set `desc.tile` of every auto-tiled 16-bit block-major igemm op with >= `min_rows` output rows to the
     fastest candidate; returns the number of distinct problems timed.  `srcs`: {op index: (x, x2)} source tensors of
     the recorded convs -- they hold scratch at this point and are filled with N(0,1) first: on zeros / NaNs the
-    chip draws less power and clocks higher, which ranks the candidates differently from real data."""
+    chip draws less power and clocks higher, which ranks the candidates differently from real data.
+    Round 4: launches with fewer rows (down to MVLDM_TUNE_SMALL_ROWS = 64: levels 2 - 4 at a few scenes, 45 % of the one-scene step,
+    which the rules alone used to serve) are tuned too, over the small tiles AND the split-K count -- at a few hundred rows the
+    number of K slices decides how much of the chip a launch fills, and the rule (fill ~512 workgroups) is one guess."""
     lib = L.load()
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -550,31 +562,43 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
         if op.kind != L.OP_IGEMM:
             continue
         d = op.u.igemm
-        if d.tile != 0 or d.act_dtype == L.F32 or d.k_order != 1 or d.n_img * d.h_out * d.w_out < min_rows:
+        rows = d.n_img * d.h_out * d.w_out
+        if d.tile != 0 or d.act_dtype == L.F32 or d.k_order != 1 or rows < min(min_rows, _SMALL_ROWS):
             continue
+        small = rows < min_rows
         key = _igemm_signature(d)
         best = _TUNE_CACHE.get(key)
         if best is None:
             trial = L.Op()
             C.memmove(C.byref(trial), C.byref(op), C.sizeof(L.Op))
+            # small launches: the 4-wave / 2-wave / 1-wave tiles x split counts (only where the op carries a split-K workspace and lets
+            # the library choose); large launches: every tile at the descriptor's own split
+            can_split = small and bool(d.workspace) and d.splitk == 0
+            cands = [(t, None) for t in _TUNE_TILES] if not small else \
+                    [(t, sk) for t in (0, 1, 2, 3, 4, 5) if t in _TUNE_TILES for sk in (_SPLITS if can_split else (None,))]
+            n_it = iters if not small else 3 * iters
             results = []
-            for tile in _TUNE_TILES:
+            for tile, sk in cands:
                 trial.u.igemm.tile = tile
+                trial.u.igemm.splitk = d.splitk if sk is None else sk
                 if lib.mvldm_op_run(C.byref(trial), stream) != 0:      # candidate not applicable to this problem
                     continue
                 e0.record()
-                for _ in range(iters):
+                for _ in range(n_it):
                     lib.mvldm_op_run(C.byref(trial), stream)
                 e1.record()
                 e1.synchronize()
-                results.append((e0.elapsed_time(e1), tile))
+                results.append((e0.elapsed_time(e1), tile, sk))
             # keep the rules' choice unless a candidate is clearly (>3 %) faster: timing noise must not flip tiles
-            t_rule = next(t for t, tile in results if tile == 0)
-            t_best, tile_best = min(results)
-            best = tile_best if t_best < 0.97 * t_rule else 0
+            t_rule = next(t for t, tile, sk in results if tile == 0 and sk in (None, 0))
+            t_best, tile_best, sk_best = min(results, key=lambda r: r[0])
+            best = [tile_best, sk_best] if t_best < 0.97 * t_rule else [0, None]
             _TUNE_CACHE[key] = best
             timed += 1
-        d.tile = best
+        tile, sk = _unpack_choice(best)
+        d.tile = tile
+        if sk is not None:
+            d.splitk = sk
     if timed:
         save_tune_cache()
     return timed
