@@ -21,7 +21,7 @@ csv.field_size_limit(1 << 30)
 
 
 def family(name: str) -> str:
-    if "linear_pp_kernel" in name or "igemm_halo_kernel" in name:      # tiles 12 / 11 of the same implicit-GEMM family
+    if "linear_pp_kernel" in name or "linear_pw_kernel" in name or "linear_ws_kernel" in name or "igemm_halo_kernel" in name:      # tiles 12 / 13 / 14 / 11 of the same implicit-GEMM family
         return "igemm"
     for key in ("igemm_bl_kernel", "igemm_kernel", "igemm_splitk_reduce", "attention_kernel",
                 "attention_wide_kernel", "attention_dsplit_kernel", "gn_fused_kernel", "gn_apply_kernel", "gn_stats_kernel", "layernorm", "eltwise", "ddim",
