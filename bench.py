@@ -129,6 +129,18 @@ def pmc_traffic(args, b, family="igemm"):
     return None if fam is None else round(fam["hbm_bytes_per_launch"])
 
 
+def train_traffic(args, b):
+    """HBM bytes of ONE run of the recorded training plan (forward + loss + backward of the accumulation window) from the committed
+    PMC passes of `bench.py --train` (tools/pmc_train_traffic.py -> profiles/pmc_traffic.json); None when no pass matches."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            ent = json.load(f).get(f"train_{args.dtype}_b{b}_res{args.res}")
+    except (OSError, ValueError):
+        return None
+    return None if ent is None else round(ent["plan"]["hbm_bytes"])
+
+
 def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params):
     """BASELINE.json configs[3]: one "step" = one optimizer step = `accumulate_grad_batches` (2) micro-batches of B scenes x
     (1 ctx + 3 tgt) views at 256x256 per GPU -- VAE encode of all views, add_noise, UNet forward, MSE, backward, then clip
@@ -195,7 +207,8 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
         fl = sum(m.flops for m in tp.plan.meta)
         out["roofline"] = {"bound": "mfma", "kernel": f"training plan, {covers} (igemm fwd / dgrad / wgrad + attention fwd / bwd)",
                            "achieved": round(fl / (sum(ms) * 1e-3) / 1e12, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                           "frac": round(fl / (sum(ms) * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4), "traffic": None}
+                           "frac": round(fl / (sum(ms) * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                           "traffic": train_traffic(args, b), "algorithmic_bytes_per_plan_run": int(sum(m.bytes for m in tp.plan.meta))}
         if args.op_table:
             with open(args.op_table, "w") as f:
                 json.dump([{"name": m.name, "kind": m.kind, "ms": t, "flops": m.flops, "bytes": m.bytes} for m, t in zip(tp.plan.meta, ms)], f, indent=0)

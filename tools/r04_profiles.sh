@@ -25,3 +25,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/f -o p -- py
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/w -o p -- python3 bench.py --unet-pass-only > /dev/null 2>&1
 python3 tools/pmc_traffic.py $(find $P/f -name p_counter_collection.csv | head -1) $(find $P/w -name p_counter_collection.csv | head -1) profiles/pmc_traffic.json 192 bf16_b64_res256 "round 4 (tools/r04_profiles.sh), the last 192 igemm dispatches of bench.py --unet-pass-only, plans from profiles/r04_tune_cache.json (no trials)" | tee $O/pmc_traffic.txt
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
+# 5. HBM-side traffic of one optimizer step of the training bench (same two counters, own passes)
+rm -rf $P
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/tf -o p -- python3 bench.py --train --steps 2 --warmup 1 --no-profile --no-parity > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/tw -o p -- python3 bench.py --train --steps 2 --warmup 1 --no-profile --no-parity > /dev/null 2>&1
+python3 tools/pmc_train_traffic.py $(find $P/tf -name p_counter_collection.csv | head -1) $(find $P/tw -name p_counter_collection.csv | head -1) profiles/pmc_traffic.json train_bf16_b4_res256 "round 4 (tools/r04_profiles.sh step 5), bench.py --train --steps 2 --warmup 1" | tee $O/pmc_train_traffic.txt
+cp profiles/pmc_traffic.json $O/pmc_traffic.json

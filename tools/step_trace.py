@@ -42,3 +42,9 @@ for _ in range(N):
     st["plan"].replay()
 torch.cuda.synchronize()
 print(f"B={B}: {1e3 * (time.perf_counter() - t0) / N:.3f} ms per DDIM step over {N} replays ({len(st['plan'].meta)} plan ops)", flush=True)
+if os.environ.get("MVLDM_OP_TABLE"):
+    import json
+    ms = st["plan"].profile(10)
+    with open(os.environ["MVLDM_OP_TABLE"], "w") as f:
+        json.dump([{"name": m.name, "kind": m.kind, "ms": t, "flops": m.flops, "bytes": m.bytes} for m, t in zip(st["plan"].meta, ms)], f, indent=0)
+    print(f"per-op table ({sum(ms):.3f} ms eager sum) -> {os.environ['MVLDM_OP_TABLE']}", flush=True)
