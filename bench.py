@@ -235,31 +235,49 @@ def other_configs(args, den, vae, dev, two_roof):
     pipe2 = MVLDMPipeline(den, vae, DDIMScheduler(clip_sample=False), SamplerCfg(True, 3.0, 25))
     pipe2.set_timesteps(25)
     ex = [G.synthetic_example(0, 80, args.res, 7)]
-    r = G.evaluate(cfg, ex, pipe=pipe2, batch_scenes=1, warmup=True)       # (warm-up: the plans of both call shapes, untimed)
-    r = G.evaluate(cfg, ex, pipe=pipe2, batch_scenes=1)
-    bound = 0.0
-    for key, st in pipe2._plans.items():
-        st["plan"].profile(1)
-        pms = st["plan"].profile(2)
-        tr = two_roof(st["plan"].meta, pms)
-        st["_two_roof"] = tr
-    # (every sample() call of the schedule replays one of these plans 25 times; calls by shape)
-    from mv_ldm_amd.schedules import anchored_schedule
+    from mv_ldm_amd.schedules import _leaf_chunks, anchored_schedule, producer_calls
     e = ex[0]
     calls = anchored_schedule(e["context"]["index"][0].tolist(), e["context"]["extrinsics"][0], e["target"]["index"][0].tolist(),
                               e["target"]["extrinsics"][0], num_anchors_views=4, ctx_intrinsics=e["context"]["intrinsics"][0],
                               tgt_intrinsics=e["target"]["intrinsics"][0])
-    for c in calls:
-        v_c, v_t = len(c.ctx_index), len(c.tgt_index)
+    prod = set(producer_calls(calls))
+
+    def leg(leaf_batch):
+        """one timed walk (after an untimed one that records + tunes its plans) and the two-roof bound of the plans it replayed"""
+        G.evaluate(cfg, ex, pipe=pipe2, batch_scenes=1, warmup=True, leaf_batch=leaf_batch)
+        r = G.evaluate(cfg, ex, pipe=pipe2, batch_scenes=1, leaf_batch=leaf_batch)
         for key, st in pipe2._plans.items():
-            if key[0] == 1 and key[1] == v_c and key[2] == v_t:
-                bound += 25 * st["_two_roof"]["bound_ms"]
-                break
+            if "_two_roof" not in st:
+                st["plan"].profile(1)
+                st["_two_roof"] = two_roof(st["plan"].meta, st["plan"].profile(2))
+        # the sample() batches of the walk: producers one by one, the independent calls `leaf_batch` at a time (by call shape)
+        batches = [(1, len(c.ctx_index), len(c.tgt_index)) for k, c in enumerate(calls) if k in prod or r["leaf_batch"] == 1]
+        if r["leaf_batch"] > 1:
+            shapes = {}
+            for k, c in enumerate(calls):
+                if k not in prod:
+                    shapes[(len(c.ctx_index), len(c.tgt_index))] = shapes.get((len(c.ctx_index), len(c.tgt_index)), 0) + 1
+            batches += [(n, v_c, v_t) for (v_c, v_t), cnt in shapes.items() for n in _leaf_chunks(cnt, r["leaf_batch"])]
+        bound = 0.0
+        for nb, v_c, v_t in batches:
+            st = next(st for key, st in pipe2._plans.items() if key[0] == nb and key[1] == v_c and key[2] == v_t)
+            bound += 25 * st["_two_roof"]["bound_ms"]
+        return r, batches, bound
+
+    r1, b1, bound1 = leg(1)          # the reference's granularity: 26 sample() calls of one scene each
+    r, bt, bound = leg(None)         # the 25 independent groups of 3 frames (SURVEY.md §8e) share sample() calls
+    same = sorted(r["frames"][ex[0]["scene"][0]]) == sorted(r1["frames"][ex[0]["scene"][0]])
     res["configs[2]"] = {"workload": f"1 scene, {len(r['frames'][ex[0]['scene'][0]])} target frames @ {args.res}x{args.res}, anchored sampling (num_anchors_views=4), "
-                                     f"25 DDIM steps, CFG 3.0, {args.dtype}, {r['sample_calls']} sample() calls incl. VAE encode / decode",
+                                     f"25 DDIM steps, CFG 3.0, {args.dtype}, the schedule's {r['sample_calls']} calls incl. VAE encode / decode; the "
+                                     f"{len(calls) - len(prod)} calls nothing depends on run {r['leaf_batch']} per sample(): {len(bt)} sample() batches "
+                                     f"{sorted(set(bt))} (generate.evaluate leaf_batch; same walk, same frame set: {same})",
                          "views_per_s": round(r["views"] / r["seconds"], 3), "seconds": round(r["seconds"], 3), "views": r["views"],
                          "two_roof": {"bound_ms": round(bound, 2), "measured_ms": round(1e3 * r["seconds"], 1),
-                                      "frac": round(bound / (1e3 * r["seconds"]), 4), "note": "UNet plans only in the bound; VAE + host schedule in the measured time"}}
+                                      "frac": round(bound / (1e3 * r["seconds"]), 4), "note": "UNet plans only in the bound; VAE + host schedule in the measured time"},
+                         "call_by_call": {"note": "leaf_batch = 1: one sample() per call like the reference's loop (26 batches of one scene)",
+                                          "views_per_s": round(r1["views"] / r1["seconds"], 3), "seconds": round(r1["seconds"], 3),
+                                          "two_roof": {"bound_ms": round(bound1, 2), "measured_ms": round(1e3 * r1["seconds"], 1),
+                                                       "frac": round(bound1 / (1e3 * r1["seconds"]), 4)}}}
     pipe2._plans.clear()
     # ---- configs[4]
     with mv_ldm_amd.compute_dtype(torch.float16):

@@ -91,7 +91,7 @@ def _sharded_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     extr, intr, img = _scene()
     calls = anchored_schedule([0], extr[:1], list(range(1, 41)), extr[1:], ctx_intrinsics=intr[:1], tgt_intrinsics=intr[1:])
-    out = run_schedule_sharded(_StubPipeline(), calls, img, rank, world, noise_seed=11)
+    out = run_schedule_sharded(_StubPipeline(), calls, img, rank, world, noise_seed=11, leaf_batch=4)     # (a rank's 6 groups: 3 + 3 per sample())
     q.put((rank, {f: v.numpy().copy() for f, v in out.items()}))      # by value (no shared-memory handles)
     dist.barrier()
     dist.destroy_process_group()
