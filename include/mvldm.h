@@ -298,8 +298,10 @@ int mvldm_colsum(const void* x, float* dst, float* workspace, size_t workspace_b
                  int ld, int ld_dst, int per_seg, int accumulate, int dtype, mvldm_stream_t stream);
 
 /* GroupNorm(+SiLU) backward (NHWC, optional two-source concat input as in the forward): dx0 / dx1 written,
- * dgamma / dbeta ACCUMULATED (+=).  stats: the forward's stats_out.  workspace: fp32,
+ * dgamma / dbeta ACCUMULATED (+=) -- or WRITTEN (=) when `silu` (here) / `dtype` (mvldm_layernorm_bwd) carries
+ * MVLDM_NORM_BWD_STORE: the first write of an accumulation window needs no zeroed gradient.  stats: the forward's stats_out.  workspace: fp32,
  * >= n_img * (MVLDM_GN_MAX_CHUNKS * (c0+c1) + groups) * 2 floats, 16-byte aligned. */
+#define MVLDM_NORM_BWD_STORE 0x100
 int mvldm_groupnorm_bwd(const void* x0, const void* x1, const void* dy, void* dx0, void* dx1, const float* gamma,
                         const float* beta, const float* stats, float* dgamma, float* dbeta, int n_img, int hw, int c0,
                         int c1, int groups, int silu, int dtype, float* workspace, size_t workspace_bytes,

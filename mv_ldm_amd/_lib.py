@@ -16,6 +16,7 @@ F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_GEGLU, EPI_GELU = 0, 1, 2, 3
 RAYS_RAW, RAYS_POSITIONAL, RAYS_SRT = 0, 1, 2
 ELT_COPY, ELT_SILU, ELT_GELU = 0, 1, 2
+NORM_BWD_STORE = 0x100          # include/mvldm.h MVLDM_NORM_BWD_STORE: norm backward writes (=) dgamma / dbeta instead of +=
 GN_MAX_CHUNKS = 32
 
 (OP_IGEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_TIMESTEP_EMBED, OP_ELTWISE, OP_DDIM_STEP, OP_DDIM_ADVANCE,

@@ -259,6 +259,8 @@ int groupnorm_bwd_run(const void* x0, const void* x1, const void* dy, void* dx0,
                       const float* stats, float* dgamma, float* dbeta, int n_img, int hw, int c0, int c1, int groups, int silu, int dtype,
                       float* ws, size_t ws_bytes, hipStream_t s) {
     if (n_img == 0 || hw == 0) return MVLDM_OK;
+    const int accumulate = (silu & MVLDM_NORM_BWD_STORE) ? 0 : 1;      // dgamma / dbeta: += (default) or = (the window's first write)
+    silu &= ~MVLDM_NORM_BWD_STORE;
     const int c = c0 + c1, epc = dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(x0 && dy && dx0 && gamma && beta && stats && dgamma && dbeta && ws, "groupnorm_bwd: null pointer");
     MVLDM_REQUIRE((c1 == 0) == (x1 == nullptr) && (c1 == 0) == (dx1 == nullptr), "groupnorm_bwd: x1/dx1/c1 mismatch");
@@ -285,7 +287,7 @@ int groupnorm_bwd_run(const void* x0, const void* x1, const void* dy, void* dx0,
                            groups, rpc, nchunk, silu);
         rc = check_launch();
         if (rc) return rc;
-        hipLaunchKernelGGL(fold_partials_kernel<1>, dim3(c * 2 / 4, 1), dim3(256), 0, s, ws, n_img * nchunk, c * 2, c * 2, dbeta, dgamma, 0, 1);
+        hipLaunchKernelGGL(fold_partials_kernel<1>, dim3(c * 2 / 4, 1), dim3(256), 0, s, ws, n_img * nchunk, c * 2, c * 2, dbeta, dgamma, 0, accumulate);
         return check_launch();
     });
 }
@@ -293,6 +295,8 @@ int groupnorm_bwd_run(const void* x0, const void* x1, const void* dy, void* dx0,
 int layernorm_bwd_run(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma, float* dbeta, int rows, int c, float eps, int dtype,
                       float* ws, size_t ws_bytes, hipStream_t s) {
     if (rows == 0) return MVLDM_OK;
+    const int accumulate = (dtype & MVLDM_NORM_BWD_STORE) ? 0 : 1;
+    dtype &= ~MVLDM_NORM_BWD_STORE;
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(x && dy && dx && gamma && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
     MVLDM_REQUIRE(c % epc == 0 && c / epc <= 64 * 8, "layernorm_bwd: c=%d", c);
@@ -317,7 +321,7 @@ int layernorm_bwd_run(const void* x, const void* dy, void* dx, const float* gamm
 #undef MVLDM_LN_BWD
         int rc = check_launch();
         if (rc) return rc;
-        hipLaunchKernelGGL(fold_partials_kernel<1>, dim3(c * 2 / 4, 1), dim3(256), 0, s, ws, blocks, c * 2, c * 2, dbeta, dgamma, 0, 1);
+        hipLaunchKernelGGL(fold_partials_kernel<1>, dim3(c * 2 / 4, 1), dim3(256), 0, s, ws, blocks, c * 2, c * 2, dbeta, dgamma, 0, accumulate);
         return check_launch();
     });
 }

@@ -10,7 +10,7 @@
 namespace mvldm {
 
 // MODE 0: out0[row * ld_out + col], col < n_valid.   MODE 1: the columns are (dbeta, dgamma) pairs of channel col / 2:
-// out0[ch] += even columns, out1[ch] += odd columns (always accumulating: parameters collect several micro-batches).
+// out0[ch] (+)= even columns, out1[ch] (+)= odd columns.  `accumulate` 0: the outputs are written (a window's first write), 1: += .
 template <int MODE>
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int P, int n, int n_valid, float* __restrict__ out0,
                                                             float* __restrict__ out1, int ld_out, int accumulate) {
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
                 *o = accumulate ? *o + t : t;
             } else {
                 float* o = ((col & 1) ? out1 : out0) + (col >> 1);
-                *o += t;
+                *o = accumulate ? *o + t : t;
             }
         }
     }

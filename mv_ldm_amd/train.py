@@ -71,9 +71,21 @@ class FlatParams:
                 p.data = self.flat[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
         self.epoch = 0
+        self.dirty: set = set()          # (offset, numel) ranges of `grad` written since the last zero_grad()
 
     def zero_grad(self):
         self.grad.zero_()
+        self.dirty.clear()
+
+    def begin_window(self, stored: set):
+        """instead of `zero_grad()` in front of a plan whose FIRST write to every range in `stored` is a store (`TrainPlan.stored`):
+        only what earlier plans wrote and this one will not overwrite is zeroed -- nothing at all in the steady state of one window
+        shape (saves the 3.7 GB fill and, in the plan, the read half of 926 M read-modify-writes).  Ranges are compared as whole
+        (offset, numel) tuples: a range written under a different fusion (one QKV gradient / three) is zeroed AND stored, which is
+        merely redundant."""
+        for off, n in sorted(self.dirty - stored):
+            self.grad[off:off + n].zero_()
+        self.dirty &= stored
 
     def wait_readers(self):
         """call before WRITING `flat` in place on the current stream: a weight re-pack launched ahead on the trainer's side stream
@@ -104,10 +116,15 @@ def _key(t: torch.Tensor):
 class TrainBuilder(Builder):
     """records forward ops like `Builder` plus, per op, a closure that emits its backward ops"""
 
-    def __init__(self, device, dtype, flat: FlatParams, ws_bytes: int = 512 << 20):
+    def __init__(self, device, dtype, flat: FlatParams, ws_bytes: int = 512 << 20, store_first: bool = False):
         assert dtype in (torch.float32, torch.bfloat16), "training runs in bf16 (fp32 accumulation / master weights) or f32"
         super().__init__(device, dtype, record=True)
         self.flat = flat
+        # plans that run ONCE per accumulation window (training_window): the first write of every gradient range is a store (grad = ...),
+        # later ones accumulate; the caller then needs no zeroed gradient buffer (FlatParams.begin_window)
+        self.store_first = bool(store_first)
+        self.grad_stored: List[bool] = []                      # per entry of grad_writes: was it emitted as a store
+        self._fw = False
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[tuple, torch.Tensor] = {}
         self.repack: List[Callable[[], None]] = []
@@ -141,17 +158,30 @@ class TrainBuilder(Builder):
         else:
             self._elt(L.TE_ADD, g, None, cur, 1, g.numel(), name="grad+=")
 
-    def _pgrad(self, p: nn.Parameter, through: Optional[nn.Parameter] = None) -> torch.Tensor:
-        """gradient view of `p` for the op ABOUT to be emitted (its plan index is len(self.ops)); the write is recorded as
-        the flat range [offset(p), offset(p) + numel) -- up to the end of `through` when one kernel fills several
-        parameters that are contiguous in the flat buffer (the fused QKV weight gradient)"""
-        self.touched.add(id(p))
+    def _range(self, p: nn.Parameter, through: Optional[nn.Parameter] = None) -> Tuple[int, int]:
         off = self.flat.offset[id(p)]
         last = p if through is None else through
-        self.touched.add(id(last))
         end = self.flat.offset[id(last)] + last.numel()
         assert end > off
-        self.grad_writes.append((len(self.ops), off, end - off))
+        return off, end - off
+
+    def _unwritten(self, p: nn.Parameter, through: Optional[nn.Parameter] = None) -> bool:
+        """may the op about to be emitted STORE into this gradient range (store_first plans: nothing emitted so far writes any of it)"""
+        off, n = self._range(p, through)
+        return self.store_first and not any(o < off + n and off < o + m for (_, o, m) in self.grad_writes)
+
+    def _pgrad(self, p: nn.Parameter, through: Optional[nn.Parameter] = None, store: Optional[bool] = None) -> torch.Tensor:
+        """gradient view of `p` for the op ABOUT to be emitted (its plan index is len(self.ops)); the write is recorded as
+        the flat range [offset(p), offset(p) + numel) -- up to the end of `through` when one kernel fills several
+        parameters that are contiguous in the flat buffer (the fused QKV weight gradient).  `self._fw` tells the caller whether
+        the op is to store (first write of the range in a store_first plan) or accumulate; `store` overrides the decision for ops
+        that fill two ranges with one flag (norm gamma / beta)."""
+        self.touched.add(id(p))
+        self.touched.add(id(p if through is None else through))
+        off, n = self._range(p, through)
+        self._fw = self._unwritten(p, through) if store is None else bool(store)
+        self.grad_writes.append((len(self.ops), off, n))
+        self.grad_stored.append(self._fw)
         return p.grad
 
     def touch(self, *ps):
@@ -186,6 +216,7 @@ class TrainBuilder(Builder):
         self._emit(op, name, 0.0, x2d.numel() * x2d.element_size(), (x2d, dst))
 
     def _wgrad(self, x, x2, dy2d, n_out, grad, geom, c_in, name):
+        """`grad` comes from `_pgrad` in the caller's argument list: `self._fw` is that range's store / accumulate decision"""
         n, h, w, c0 = x.shape
         op = L.Op()
         op.kind = L.OP_WGRAD
@@ -195,7 +226,7 @@ class TrainBuilder(Builder):
         d.c0, d.c1, d.c_in = c0, 0 if x2 is None else x2.shape[-1], c_in
         d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, geom["ho"], geom["wo"]
         d.ksize, d.stride, d.pad, d.upsample = geom["ksize"], geom["stride"], geom["pad"], int(geom["upsample"])
-        d.n_out, d.dy_ld, d.act_dtype, d.accumulate = n_out, dy2d.stride(0), dt(x), 1
+        d.n_out, d.dy_ld, d.act_dtype, d.accumulate = n_out, dy2d.stride(0), dt(x), 0 if self._fw else 1
         m = n * geom["ho"] * geom["wo"]
         k = geom["ksize"] ** 2 * (c0 + d.c1)
         self._emit(op, name, 2.0 * m * n_out * k, (m * (n_out + k / geom["ksize"] ** 2)) * x.element_size() + n_out * k * 4.0, (x, x2, dy2d, grad))
@@ -289,7 +320,7 @@ class TrainBuilder(Builder):
                 for i, w in enumerate(weights):
                     if biases:
                         for p in biases[i]:
-                            self._colsum(dy[:, off:off + n_i[i]], n_i[i], self._pgrad(p), n_i[i], rows, False, True, "dbias")
+                            self._colsum(dy[:, off:off + n_i[i]], n_i[i], self._pgrad(p), n_i[i], rows, False, not self._fw, "dbias")
                     off += n_i[i]
                 geom = dict(ho=1, wo=1, ksize=1, stride=1, pad=0, upsample=False)
                 if len(weights) == 1 or self.flat.contiguous(list(weights)):
@@ -336,7 +367,7 @@ class TrainBuilder(Builder):
             dy2d = dy.view(n * ho * wo, dy.shape[-1])
             with self.scope("bwd/" + name):
                 if bias_p is not None:
-                    self._colsum(dy2d, co, self._pgrad(bias_p), co, n * ho * wo, False, True, "dbias")
+                    self._colsum(dy2d, co, self._pgrad(bias_p), co, n * ho * wo, False, not self._fw, "dbias")
                 if row_bias is not None:      # gradient of the per-image time-embedding row: column sums per image
                     self._colsum(dy2d, co, row_bias[1], row_bias[1].stride(0), ho * wo, True, False, "d_temb_row")
                 self._wgrad(x, x2, dy2d, co, self._pgrad(weight), geom, c_in, "wgrad")
@@ -390,9 +421,11 @@ class TrainBuilder(Builder):
             op.kind = L.OP_GROUPNORM_BWD
             g = op.u.groupnorm_bwd
             g.x0, g.x1, g.dy, g.dx0, g.dx1 = ptr(x), ptr(x2), ptr(dy), ptr(dx), ptr(dx2)
-            g.gamma, g.beta, g.stats, g.dgamma, g.dbeta = ptr(gamma.data), ptr(beta.data), ptr(stats), ptr(self._pgrad(gamma)), ptr(self._pgrad(beta))
+            st = self._unwritten(gamma) and self._unwritten(beta)      # one flag for both outputs (MVLDM_NORM_BWD_STORE rides in `silu`)
+            g.gamma, g.beta, g.stats, g.dgamma, g.dbeta = (ptr(gamma.data), ptr(beta.data), ptr(stats), ptr(self._pgrad(gamma, store=st)),
+                                                           ptr(self._pgrad(beta, store=st)))
             g.workspace, g.workspace_bytes = ptr(self._wws), self._wws.numel()
-            g.n_img, g.hw, g.c0, g.c1, g.groups, g.silu, g.dtype = n, hw, c0, c1, mod.num_groups, int(silu), dt(x)
+            g.n_img, g.hw, g.c0, g.c1, g.groups, g.silu, g.dtype = n, hw, c0, c1, mod.num_groups, int(silu) | (L.NORM_BWD_STORE if st else 0), dt(x)
             self._emit(op, "bwd/" + name, 0.0, 5.0 * dy.numel() * dy.element_size(), (x, x2, dy, dx, dx2, stats))
             self.add_grad(x, dx)
             self.add_grad(x2, dx2)
@@ -413,9 +446,11 @@ class TrainBuilder(Builder):
             op = L.Op()
             op.kind = L.OP_LAYERNORM_BWD
             l = op.u.layernorm_bwd
-            l.x, l.dy, l.dx, l.gamma, l.dgamma, l.dbeta = ptr(x), ptr(dy), ptr(dx), ptr(gamma.data), ptr(self._pgrad(gamma)), ptr(self._pgrad(beta))
+            st = self._unwritten(gamma) and self._unwritten(beta)      # (MVLDM_NORM_BWD_STORE rides in `dtype`)
+            l.x, l.dy, l.dx, l.gamma, l.dgamma, l.dbeta = (ptr(x), ptr(dy), ptr(dx), ptr(gamma.data), ptr(self._pgrad(gamma, store=st)),
+                                                           ptr(self._pgrad(beta, store=st)))
             l.workspace, l.workspace_bytes = ptr(self._wws), self._wws.numel()
-            l.rows, l.c, l.dtype, l.eps = x.numel() // c, c, dt(x), mod.eps
+            l.rows, l.c, l.dtype, l.eps = x.numel() // c, c, dt(x) | (L.NORM_BWD_STORE if st else 0), mod.eps
             self._emit(op, "bwd/" + name, 0.0, 3.0 * dy.numel() * dy.element_size(), (x, dy, dx))
             self.add_grad(x, dx)
         self.tape.append(backward)
@@ -689,7 +724,9 @@ class TrainPlan:
     micro-batches one by one adds up to), the weights are read once, and every launch serves the whole window."""
 
     def __init__(self, den, flat: FlatParams, b, v_c=None, v_t=None, hl: int = 0, wl: int = 0, dtype=torch.bfloat16, loss_scale: float = 1.0,
-                 grad_scale: float = 1.0, graph: bool = False, rays=None, tune: Optional[bool] = None):
+                 grad_scale: float = 1.0, graph: bool = False, rays=None, tune: Optional[bool] = None, store_first: bool = False):
+        """`store_first`: the plan runs once per accumulation window and its first write of every gradient range is a store -- the
+        caller replaces `flat.zero_grad()` by `flat.begin_window(plan.stored)`"""
         dev = flat.flat.device
         if tune is None:        # plan-time tile selection of the forward / data-gradient implicit GEMMs (MVLDM_TRAIN_AUTOTUNE=0: rules only)
             tune = os.environ.get("MVLDM_TRAIN_AUTOTUNE", "1") != "0" and os.environ.get("MVLDM_AUTOTUNE", "1") != "0"
@@ -711,7 +748,8 @@ class TrainPlan:
             n_img += pb * v
             n_tgt += pb * pt
         self.n_img, self.n_tgt = n_img, n_tgt
-        bld = TrainBuilder(dev, dtype, flat)
+        bld = TrainBuilder(dev, dtype, flat, store_first=store_first)
+        self.flat, self.store_first = flat, bool(store_first)
         z = lambda *s_, dt_=torch.float32: torch.zeros(*s_, dtype=dt_, device=dev)
         # ---- inputs staged by the host (copies), assembled by HIP kernels (diffusion_wrapper.py:362-398) ----
         self.latents = z(n_img, lc, hl, wl)            # first_stage_encode of [context | target] views, per scene
@@ -757,6 +795,8 @@ class TrainPlan:
         assert not bld.tape
         self.eps, self.unet_in, self.tgt_img = eps, unet_in, tgt_img
         self.touched, self.grad_writes, self.repack = bld.touched, bld.grad_writes, bld.repack
+        self.written = {(o, n_) for (_, o, n_) in bld.grad_writes}                                        # gradient ranges this plan writes
+        self.stored = {(o, n_) for (_, o, n_), st in zip(bld.grad_writes, bld.grad_stored) if st}        # ... whose first write is a store
         self.pack_jobs, self._pack_dtype = bld.pack_jobs, dtype
         self._pack_batch = ops.PackBatch(bld.pack_jobs, dtype, dev) if os.environ.get("MVLDM_TRAIN_PACK_BATCH", "1") != "0" else None
         self.plan: Plan = bld.finalize(autotune=tune)
@@ -778,6 +818,7 @@ class TrainPlan:
                                                    dt(self._pack_dtype), j.transpose, j.c_off, j.n_rows, ops.stream()))
 
     def run(self, first: int = 0, last: Optional[int] = None):
+        self.flat.dirty |= self.written
         if self.graph and first == 0 and last is None:
             self.plan.replay()
         else:
@@ -1061,8 +1102,12 @@ class MVLDMTrainer:
             acc = self.cfg.accumulate_grad_batches
             use_graph = self.graph and not self.opt.collective
             saved = self.flat.grad.clone() if use_graph else None       # a plan recorded mid-accumulation must not disturb it
+            # a window plan (one part per micro-batch) runs once per optimizer step: its first write of every gradient range is a store
+            # and `training_window` skips the zero_grad (MVLDM_TRAIN_STORE_FIRST=0: accumulate into a zeroed buffer like the
+            # micro-batch plans, A/B knob)
+            store = len(parts) > 1 and os.environ.get("MVLDM_TRAIN_STORE_FIRST", "1") != "0"
             tp = TrainPlan(self.denoiser, self.flat, parts, None, None, hl, wl, self.dtype, loss_scale=1.0 / acc,
-                           grad_scale=1.0 / (acc * self.world), graph=use_graph, rays=self.rays)
+                           grad_scale=1.0 / (acc * self.world), graph=use_graph, rays=self.rays, store_first=store)
             if saved is not None:
                 self.flat.grad.copy_(saved)
                 tp.loss.zero_()
@@ -1237,10 +1282,13 @@ class MVLDMTrainer:
         hl, wl = next(iter(hw))
         if self.ema is not None:
             self.ema.update()
-        self.flat.zero_grad()
+        tp = self.plan_for_parts([(p_["b"], p_["vc_eff"], p_["v_t"]) for p_ in parts], hl, wl)
+        if tp.store_first:
+            self.flat.begin_window(tp.stored)       # (nothing to zero in the steady state: every range's first write is a store)
+        else:
+            self.flat.zero_grad()
         for tp_ in self.plans.values():
             tp_.loss.zero_()
-        tp = self.plan_for_parts([(p_["b"], p_["vc_eff"], p_["v_t"]) for p_ in parts], hl, wl)
         for i, p_ in enumerate(parts):
             self._stage_part(tp, i, p_)
         self._fresh(tp)

@@ -156,6 +156,54 @@ def test_accumulation_window_as_one_plan_equals_micro_batch_steps(golden, dtype)
         assert float((w0 - w1).abs().max()) < 2e-5          # one AdamW step of lr 1e-3 from (almost) the same gradients
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_window_plan_stores_its_first_gradient_write_instead_of_zero_grad(golden, dtype, monkeypatch):
+    """window plans (one run per optimizer step) emit the first write of every gradient range as a store and `training_window` skips
+    `zero_grad()` (FlatParams.begin_window): bit-identical gradients to the accumulate-into-zeros form (MVLDM_TRAIN_STORE_FIRST=0),
+    over two consecutive windows of different shapes (the second must not see the first one's gradients), from a POISONED gradient
+    buffer (every stored range really is overwritten), and with stale ranges the plan does not store (zeroed by begin_window)."""
+    from mv_ldm_amd.train import OptimizerCfg
+    g = golden("g9_training_step")
+    cases = [g9_case(g, ci) for ci in (0, 2)]
+    windows = [([cases[0][0], cases[1][0]], [hip_choices(cases[0][1]), hip_choices(cases[1][1])]),
+               ([cases[1][0], cases[1][0]], [hip_choices(cases[1][1]), hip_choices(cases[1][1])])]
+    got = {}
+    for mode in ("0", "1", "poison"):
+        monkeypatch.setenv("MVLDM_TRAIN_STORE_FIRST", "0" if mode == "0" else "1")
+        tr = build_trainer(g, dtype, optimizer_cfg=OptimizerCfg(lr=1e-3))
+        out = []
+        for wi, (bts, chs) in enumerate(windows):
+            if mode == "poison":
+                tr.flat.grad.fill_(7.0)                         # garbage everywhere ...
+                if wi == 0:
+                    tr.flat.dirty = {(0, tr.flat.numel)}        # ... declared: whatever the plan does not store gets zeroed
+                # (second window: only the ranges the first window wrote are dirty -- all of them are stored again or zeroed; the
+                #  rest of the buffer must be restored by hand: nobody is allowed to write there without saying so)
+                if wi == 1:
+                    keep = torch.zeros_like(tr.flat.grad, dtype=torch.bool)
+                    for off, n in tr.flat.dirty:
+                        keep[off:off + n] = True
+                    tr.flat.grad[~keep] = 0.0
+            losses = [float(x) for x in tr.training_window(bts, chs)]
+            torch.cuda.synchronize()
+            tp = list(tr.plans.values())[-1]
+            assert tp.store_first == (mode != "0") and len(tp.parts) == 2
+            if mode != "0":
+                assert tp.stored and tp.stored <= tp.written
+                # every parameter-gradient write of this plan is covered by a store: nothing is left to accumulate into stale memory
+                cover = torch.zeros(tr.flat.numel, dtype=torch.bool)
+                for off, n in tp.stored:
+                    cover[off:off + n] = True
+                assert all(bool(cover[off:off + n].all()) for off, n in tp.written)
+            out.append((losses, tr.flat.grad.clone(), float(tr.opt.norm[0]), tr.flat.flat.clone()))
+        got[mode] = out
+    for mode in ("1", "poison"):
+        for wi in range(2):
+            (l0, g0, n0, w0), (l1, g1, n1, w1) = got["0"][wi], got[mode][wi]
+            assert l0 == l1 and n0 == n1, (mode, wi, l0, l1, n0, n1)
+            assert torch.equal(g0, g1) and torch.equal(w0, w1), (mode, wi, float((g0 - g1).abs().max()))
+
+
 def test_plan_owns_every_workspace_its_ops_point_into(golden):
     """the recorded training plan outlives the builder that made it: every scratch pointer inside its weight-gradient / column-sum /
     norm-backward ops must lie in a tensor the plan itself keeps alive (a builder-owned workspace would go back to the caching
