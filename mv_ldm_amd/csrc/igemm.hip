@@ -648,6 +648,20 @@ __device__ __forceinline__ void bl_compute(const char* stage_base, f32x16 (&acc)
     }
 }
 
+// s_waitcnt vmcnt(min(young, MAXY) * LPT) lgkmcnt(0): `young` tiles of LPT loads per wave may stay in flight behind the awaited one
+template <int LPT, int MAXY>
+__device__ __forceinline__ void bl_wait_young(int young) {
+    if constexpr (MAXY >= 1) {
+        if (young >= MAXY) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXY * LPT) : "memory");
+            return;
+        }
+        bl_wait_young<LPT, MAXY - 1>(young);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int STAGES, bool UPS>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams p) {
     using M_ = Mma<T>;
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW, LPT = A_IT + B_IT;
     static_assert(A_IT >= 1 && B_IT >= 1 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "bad tile");
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 8, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -773,9 +787,42 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
         slot_c ^= 1;                                                                                              \
     }
+    // Deep ring (STAGES >= 4, the small-launch tiles 16 - 18): tiles t+1 .. t+STAGES-1 are in flight while tile t is consumed.  With a
+    // few hundred output rows a K-tile is a handful of MFMAs, so a step of the 2-slot loop costs one exposed L2 / HBM round trip
+    // (the 4x4-level convs of one scene: 18 steps x ~0.8 us for 30 MB of weights); here the round trip is shared by STAGES - 1 steps.
+#define MVLDM_BL_STEP_DEEP(t_)                                                                                    \
+    {                                                                                                             \
+        bl_wait_young<LPT, STAGES - 2>((cb1 - cb) * TAPS - (t_) - 1);      /* tile t has landed (younger ones stay in flight) */ \
+        __builtin_amdgcn_s_barrier();                                      /* ... for every wave, and tile t-1's slot is free */ \
+        {                                                                                                         \
+            const int cbn_ = cb + ((t_) + STAGES - 1) / TAPS;                                                     \
+            if (cbn_ < cb1) { MVLDM_BL_ISSUE(slot_c == 0 ? STAGES - 1 : slot_c - 1, cbn_, MVLDM_BL_NEXT(t_, STAGES - 1)); } \
+        }                                                                                                         \
+        bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
+        slot_c = slot_c + 1 == STAGES ? 0 : slot_c + 1;                                                           \
+    }
+#define MVLDM_BL_PRO(j_)                                                                                          \
+    if constexpr (STAGES - 1 > (j_)) {                                                                            \
+        if (cb0 + (j_) / TAPS < cb1) { MVLDM_BL_ISSUE((j_), cb0 + (j_) / TAPS, ((j_) % TAPS)); }                  \
+    }
     // (the pipelined form needs 2 x (TM + TN) fragments next to the accumulators: not with 10 accumulator blocks)
-    constexpr bool PIPE = NW == 8 && TM * TN <= 8;
-    if constexpr (!PIPE) {
+    constexpr bool PIPE = NW == 8 && TM * TN <= 8 && STAGES <= 3;
+    if constexpr (STAGES > 3) {
+        static_assert((STAGES - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
+        if (cb0 < cb1) {
+            MVLDM_BL_ISSUE(0, cb0, 0);
+            MVLDM_BL_PRO(1) MVLDM_BL_PRO(2) MVLDM_BL_PRO(3) MVLDM_BL_PRO(4) MVLDM_BL_PRO(5) MVLDM_BL_PRO(6)
+            int slot_c = 0;
+            for (int cb = cb0; cb < cb1; ++cb) {
+                MVLDM_BL_STEP_DEEP(0)
+                if constexpr (TAPS == 4) { MVLDM_BL_STEP_DEEP(1) MVLDM_BL_STEP_DEEP(2) MVLDM_BL_STEP_DEEP(3) }
+                if constexpr (TAPS == 9) {
+                    MVLDM_BL_STEP_DEEP(1) MVLDM_BL_STEP_DEEP(2) MVLDM_BL_STEP_DEEP(3) MVLDM_BL_STEP_DEEP(4)
+                    MVLDM_BL_STEP_DEEP(5) MVLDM_BL_STEP_DEEP(6) MVLDM_BL_STEP_DEEP(7) MVLDM_BL_STEP_DEEP(8)
+                }
+            }
+        }
+    } else if constexpr (!PIPE) {
         static_assert(STAGES == 2, "the plain loop uses the 2-slot ring");
         if (cb0 < cb1) {
             MVLDM_BL_ISSUE(0, cb0, 0);
@@ -814,6 +861,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         }
     }
 #undef MVLDM_BL_STEP_SIMPLE
+#undef MVLDM_BL_STEP_DEEP
+#undef MVLDM_BL_PRO
 #undef MVLDM_BL_LOAD
 #undef MVLDM_BL_MMA
 #undef MVLDM_BL_NEXT
@@ -1061,7 +1110,32 @@ template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce
         float a[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = g[e] = 0.f;
-        for (int s = 0; s < p.splitk; ++s) {
+        // the slabs are summed in split order (fixed: same bits on every run), FOUR slabs' loads in flight at a time: with one slab per
+        // iteration every add waited for its own L2 round trip -- 10 splits = 10 dependent latencies = 5-6 us for a 7 MB read
+        // (rocprofv3, the 4x4-level convs of one scene), as long as a third of the GEMM it finishes
+        int s = 0;
+        for (; s + 4 <= p.splitk; s += 4) {
+            f32x4 lo[4], hi[4], gl[4], gh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                lo[u] = *reinterpret_cast<const f32x4*>(w0 + (s + u) * slab);
+                hi[u] = *reinterpret_cast<const f32x4*>(w0 + (s + u) * slab + 4);
+                if (geglu) {
+                    gl[u] = *reinterpret_cast<const f32x4*>(w0 + (s + u) * slab + 32);
+                    gh[u] = *reinterpret_cast<const f32x4*>(w0 + (s + u) * slab + 36);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] += lo[u][e]; a[4 + e] += hi[u][e]; }
+                if (geglu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { g[e] += gl[u][e]; g[4 + e] += gh[u][e]; }
+                }
+            }
+        }
+        for (; s < p.splitk; ++s) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(w0 + s * slab), hi = *reinterpret_cast<const f32x4*>(w0 + s * slab + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { a[e] += lo[e]; a[4 + e] += hi[e]; }
@@ -1264,8 +1338,13 @@ static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64
                                  {256, 256, 512},    // tile 9: 8 waves of 64x128, 2-deep ring (128 KB): 128 flop per L2->LDS byte
                                  {256, 320, 512},    // tile 10: 8 waves of 64x160 -- every channel count of this UNet is a
                                                      // multiple of 320 (no N padding); 142 flop per L2->LDS byte
-                                 {256, 128, 512}};   // tile 11: 256x128 with the LDS-resident pixel halo (3x3 stride-1 convs)
+                                 {256, 128, 512},    // tile 11: 256x128 with the LDS-resident pixel halo (3x3 stride-1 convs)
+                                 {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},      // 12 - 14: linear_pp / linear_pw / linear_ws (own files); 15 unused
+                                 {0, 0, 0}, {0, 0, 0},     // 16 / 17: deep-ring forms of tiles 2 / 4, measured slower, not built
+                                 // deep-ring tile for launches of a few hundred rows (weight-bound: levels 2 - 4 at a few scenes):
+                                 {192, 128, 512}};   // tile 18: 8 waves of 96x32, 4 slots (160 KB): <= 192 rows read every weight byte once
 constexpr int kNumTiles = 11;
+static inline bool deep_tile(int tile) { return tile == 18; }
 
 // tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
 // target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
@@ -1311,12 +1390,12 @@ static int launch_bl_s(const IgemmParams& p, hipStream_t s) {
     return launch_kernel(igemm_bl_kernel<T, BM, BN, WM, WN, KS, DUAL, STAGES, UPS>, done, ring > park ? ring : park,
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
-template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL>
+template <typename T, int BM, int BN, int WM, int WN, int KS, bool DUAL, int DEPTH = 0>
 static int launch_bl(const IgemmParams& p, hipStream_t s) {
     // ring depth is fixed per tile (sweeps in profiles/r01_igemm_sweep*.json): the 4-wave tiles run 2-3
     // workgroups per CU and lose more to a third slot than they gain; the 8-wave 256x128 / 128x256 tiles own
-    // the CU and take 3 slots; 256x256 only has room for 2
-    constexpr int STAGES = (WM * WN == 8 && 3 * (BM + BN) * 128 <= 160 * 1024) ? 3 : 2;
+    // the CU and take 3 slots; 256x256 only has room for 2.  DEPTH > 0: the deep-ring tiles (16 - 18) name theirs.
+    constexpr int STAGES = DEPTH ? DEPTH : ((WM * WN == 8 && 3 * (BM + BN) * 128 <= 160 * 1024) ? 3 : 2);
     if (p.upsample) {
         // per-tap address tables: only built for the two tiles the host maps upsampling convs to
         if constexpr (KS == 3 && !DUAL && ((BM == 128 && BN == 64) || (BM == 256 && BN == 128)))
@@ -1326,6 +1405,14 @@ static int launch_bl(const IgemmParams& p, hipStream_t s) {
     }
     return launch_bl_s<T, BM, BN, WM, WN, KS, DUAL, STAGES, false>(p, s);
 }
+// the deep-ring tiles: 1x1 / 3x3, one or two sources, no upsampling forms (fill_params maps those to tile 2)
+template <typename T, int BM, int BN, int WM, int WN, int DEPTH> static int launch_bl_deep(const IgemmParams& p, hipStream_t s) {
+    const bool dual = p.c1 > 0;
+    if (p.ksize == 3) return dual ? launch_bl<T, BM, BN, WM, WN, 3, true, DEPTH>(p, s) : launch_bl<T, BM, BN, WM, WN, 3, false, DEPTH>(p, s);
+    if (p.ksize == 1) return dual ? launch_bl<T, BM, BN, WM, WN, 1, true, DEPTH>(p, s) : launch_bl<T, BM, BN, WM, WN, 1, false, DEPTH>(p, s);
+    return set_error(MVLDM_ERR_ARG, "igemm: the deep-ring tiles take 1x1 and 3x3 convs");
+}
+
 template <typename T, int BM, int BN, int WM, int WN> static int launch_bl_any(const IgemmParams& p, hipStream_t s) {
     const bool dual = p.c1 > 0;
     if (p.ksize == 2) {   // the four 2x2 phases of a decomposed nearest-2x upsampling conv: tiles 2, 7 and 10 only
@@ -1410,6 +1497,14 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
                 if (p.use_bl) return launch_halo<T>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 11 needs the 16-bit block-major path");
+        case 18:
+            // (tiles 16 / 17 -- 128x64 with 5 slots, 64x64 with 6 -- were built and measured SLOWER than their 2-slot forms on every
+            //  one-scene shape (tools/skinny_probe.py: 25.2 / 30.2 us against 22.0 / 21.8 on the 4x4-level conv): several 2-slot
+            //  workgroups per CU already overlap each other's round trips; not instantiated)
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl && !p.upsample) return launch_bl_deep<T, 192, 128, 2, 4, 4>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 18 needs the 16-bit block-major path (no upsampling forms)");
         default: return set_error(MVLDM_ERR_ARG, "igemm: bad tile %d", tile);
     }
 }
@@ -1496,11 +1591,11 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
     MVLDM_REQUIRE(p.dst_ld >= p.n_dst, "igemm: dst_ld %d < n_dst %d", p.dst_ld, p.n_dst);
     p.k_tiles = d.k_pad / bk;
-    tile = d.tile & 15;
+    tile = d.tile & 63;
     t_force_sync = (d.tile >> 12) & 1;
     const int force_px = (d.tile >> 8) & 15;
     int splitk = d.splitk;
-    MVLDM_REQUIRE(tile >= 0 && tile <= kNumTiles && splitk >= 0, "igemm: tile/splitk");
+    MVLDM_REQUIRE(((tile >= 0 && tile <= kNumTiles) || deep_tile(tile)) && splitk >= 0, "igemm: tile/splitk");
     choose_config(d, p.M, p.k_tiles, tile, splitk, d.workspace_bytes);
     // (a phase conv may split K like any other: its partial slabs are indexed by the LOW-resolution row and the reduce kernel scatters)
     if (splitk > 1)
@@ -1531,6 +1626,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     if (kEnvFake & 1) p.src0_bytes = p.src1_bytes = 0;   // EXPERIMENT ONLY: every A piece fails the range check (zeros, no L2 traffic)
     if (kEnvFake & 2) p.w_bytes = 0;                     // same for W
     if (tile >= 6 && !p.use_bl) tile = 2;
+    if (deep_tile(tile) && d.upsample) tile = 2;      // (no per-tap tables / phase scatter in the deep-ring instantiations)
     p.splitk = splitk;
     if (p.use_bl) {   // splits own whole channel blocks (all taps of a block stay together)
         const int cbs = p.k_tiles / p.taps;
@@ -1543,7 +1639,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     }
     // LDS-staged epilogue: 16-byte rows need 8-column alignment of the 16-bit output (or a split-K slab)
     p.stage_epi = p.use_bl && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
-    if (tile >= 9 && (!p.stage_epi || (tile == 10 && d.epilogue == MVLDM_EPI_GEGLU))) tile = 7;   // no per-element epilogue there; odd TN cannot pair GEGLU columns
+    if (tile >= 9 && tile <= 10 && (!p.stage_epi || (tile == 10 && d.epilogue == MVLDM_EPI_GEGLU))) tile = 7;   // no per-element epilogue there; odd TN cannot pair GEGLU columns
     if (tile == 11 && !(p.use_bl && p.stage_epi && p.splitk == 1 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
                         d.h_out == d.h_in && d.w_out == d.w_in && halo_rows_for(d.w_in) <= 384 &&
                         2 * halo_rows_for(d.w_in) * 128 + 3 * 128 * 128 + 1152 <= 160 * 1024))
@@ -1609,15 +1705,15 @@ int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
     IgemmParams p;
     int tile = 0;
     if (d.n_img == 0 || d.h_out == 0 || d.w_out == 0) return MVLDM_OK;   // empty batch: nothing to do (its buffers may be null)
-    if ((d.tile & 15) == 12) {
+    if ((d.tile & 63) == 12) {
         MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
         return linear_pp_run(d, s);
     }
-    if ((d.tile & 15) == 13) {
+    if ((d.tile & 63) == 13) {
         MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
         return linear_pw_run(d, s);
     }
-    if ((d.tile & 15) == 14) {
+    if ((d.tile & 63) == 14) {
         MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
         return linear_ws_run(d, s);
     }

@@ -529,6 +529,9 @@ def _igemm_signature(d) -> tuple:
 
 _SMALL_ROWS = int(os.environ.get("MVLDM_TUNE_SMALL_ROWS", "64"))       # launches below this many output rows keep the rules
 _SPLITS = (0, 1, 2, 4, 8, 16, 32)
+# tiles tried on small launches: the 1 / 2 / 4-wave tiles and tile 18 (192x128, 4-slot ring: up to 192 rows read every weight byte once; wins
+# the wide GEGLU projections at 8x8).  The tall 2-slot tiles 6 / 7 (256x64, 256x128) were tried and never picked (tools/skinny_probe.py).
+_SMALL_TILES = tuple(int(t) for t in os.environ.get("MVLDM_TUNE_SMALL_TILES", "0,1,2,3,4,5,18").split(","))
 
 
 def _unpack_choice(v):
@@ -575,7 +578,7 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
             # the library choose); large launches: every tile at the descriptor's own split
             can_split = small and bool(d.workspace) and d.splitk == 0
             cands = [(t, None) for t in _TUNE_TILES] if not small else \
-                    [(t, sk) for t in (0, 1, 2, 3, 4, 5) if t in _TUNE_TILES for sk in (_SPLITS if can_split else (None,))]
+                    [(t, sk) for t in _SMALL_TILES if t in _TUNE_TILES or not os.environ.get("MVLDM_TUNE_TILES") for sk in (_SPLITS if can_split else (None,))]
             n_it = iters if not small else 3 * iters
             results = []
             for tile, sk in cands:

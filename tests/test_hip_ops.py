@@ -106,7 +106,7 @@ def test_conv_tiles_and_splitk(ops, dtype):
     ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
     pw = ops.pack_weight(wt.cuda(), dtype)
     xg = nhwc(x, dtype)
-    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
+    tiles = (1, 2, 3, 4, 5) if dtype == torch.float32 else (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 18)
     for tile in tiles:
         for sk in (1, 2, 5):
             y = ops.conv2d(xg, pw, b.cuda(), tile=tile, splitk=sk)
@@ -180,9 +180,43 @@ def test_geglu(ops, dtype, rows, c):
         assert y.shape == (rows, 4 * c)
         close(y.float().cpu().double(), ref, dtype, f"geglu splitk{sk}")
     if dtype != torch.float32:   # the 8-wave tiles (staged epilogue only) with the GEGLU column pairing
-        for tile in (1, 7, 8, 9):
+        for tile in (1, 7, 8, 9, 18):
             y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=tile)
             close(y.float().cpu().double(), ref, dtype, f"geglu tile{tile}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_deep_ring_tile_for_small_launches(ops, dtype):
+    """tile 18 (192 x 128, 8 waves of 96 x 32, 4-slot ring: the weight-bound launches of a few scenes -- up to 192 rows fetch every
+    weight byte once): 3x3 conv at the 4x4 / 8x8 level shapes of one scene (ragged row tiles: 144 and 576 rows), K longer and shorter
+    than the ring (1 .. 20 channel blocks x 9 taps), split-K, the skip-concat 1x1 shortcut (two sources), Linear with bias +
+    residual; against fp64 and bit-identical to tile 7 (same MFMA K order and epilogue) where both apply"""
+    for (n, h, cin, cout) in ((9, 4, 1280, 320), (9, 8, 64, 128), (9, 8, 192, 192)):
+        x, wt = rnd((n, cin, h, h), 71, dtype), rnd((cout, cin, 3, 3), 72, dtype, 1 / math.sqrt(cin * 9))
+        b = torch.randn(cout, generator=G(73)) * 0.1
+        ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+        pw = ops.pack_weight(wt.cuda(), dtype)
+        xg = nhwc(x, dtype)
+        for sk in (1, 3, 0):
+            y = ops.conv2d(xg, pw, b.cuda(), tile=18, splitk=sk)
+            close(nchw(y), ref, dtype, f"conv3x3 {cin}->{cout} @ {h}x{h} tile18/splitk{sk}")
+        assert torch.equal(ops.conv2d(xg, pw, b.cuda(), tile=18, splitk=1), ops.conv2d(xg, pw, b.cuda(), tile=7, splitk=1))
+    # two sources (never-materialised channel concat), 1x1
+    n, h, c0, c1, cout = 9, 8, 128, 64, 256
+    x, x2 = rnd((n, c0, h, h), 74, dtype), rnd((n, c1, h, h), 75, dtype)
+    wt = rnd((cout, c0 + c1, 1, 1), 76, dtype, 1 / math.sqrt(c0 + c1))
+    b = torch.randn(cout, generator=G(77)) * 0.1
+    ref = F.conv2d(torch.cat([x, x2], 1).double(), wt.double(), b.double())
+    pw = ops.pack_weight(wt[:, :, 0, 0].cuda(), dtype, c_split=c0)
+    close(nchw(ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=nhwc(x2, dtype), tile=18)), ref, dtype, "dual-source 1x1 tile18")
+    # Linear + bias + residual, rows not a multiple of 192, N not a multiple of 128
+    rows, cin, cout = 577, 1280, 320
+    x, wt, res = rnd((rows, cin), 78, dtype), rnd((cout, cin), 79, dtype, 1 / math.sqrt(cin)), rnd((rows, cout), 80, dtype)
+    b = torch.randn(cout, generator=G(81)) * 0.1
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    for sk in (1, 4):
+        y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), residual=res.to(dtype).cuda(), tile=18, splitk=sk)
+        close(y.float().cpu().double(), F.linear(x.double(), wt.double(), b.double()) + res.double(), dtype, f"linear+res tile18/splitk{sk}")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
