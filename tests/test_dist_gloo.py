@@ -254,6 +254,7 @@ def test_recorded_gradient_writes_cover_every_trained_parameter_exactly():
     flat = FlatParams(m)
     tb = TrainBuilder.__new__(TrainBuilder)            # bookkeeping only: no device, no ops
     tb.flat, tb.touched, tb.grad_writes, tb.ops = flat, set(), [], [None] * 5
+    tb.store_first, tb.grad_stored, tb._fw = False, [], False
     g = tb._pgrad(m.to_q.weight, through=m.to_v.weight)
     assert g is m.to_q.weight.grad
     assert tb.grad_writes == [(5, flat.offset[id(m.to_q.weight)], 3 * 64)]
@@ -261,6 +262,49 @@ def test_recorded_gradient_writes_cover_every_trained_parameter_exactly():
     tb.ops.append(None)
     tb._pgrad(m.n.bias)
     assert tb.grad_writes[-1] == (6, flat.offset[id(m.n.bias)], 8)
+    assert tb.grad_stored == [False, False] and not tb._fw           # an accumulating plan never stores
+
+
+def test_store_first_bookkeeping_and_begin_window():
+    """window plans (TrainBuilder(store_first=True)): the FIRST recorded write of a gradient range is a store, any later write that
+    overlaps it -- the same parameter, or one parameter of a fused range -- accumulates; `FlatParams.begin_window(stored)` zeroes
+    exactly the ranges earlier plans wrote that this plan does not store, `zero_grad()` forgets them all"""
+    from mv_ldm_amd.train import FlatParams, TrainBuilder
+    import torch.nn as nn
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.to_q, self.to_k, self.to_v = nn.Linear(8, 8, bias=False), nn.Linear(8, 8, bias=False), nn.Linear(8, 8, bias=False)
+            self.n = nn.LayerNorm(8)
+    m = Tiny()
+    flat = FlatParams(m)
+    tb = TrainBuilder.__new__(TrainBuilder)
+    tb.flat, tb.touched, tb.grad_writes, tb.ops = flat, set(), [], []
+    tb.store_first, tb.grad_stored, tb._fw = True, [], False
+    tb._pgrad(m.to_q.weight, through=m.to_v.weight)
+    assert tb._fw                                                       # the fused QKV range: first write, a store
+    tb._pgrad(m.to_k.weight)
+    assert not tb._fw                                                   # inside the fused range: accumulates
+    st = tb._unwritten(m.n.weight) and tb._unwritten(m.n.bias)
+    tb._pgrad(m.n.weight, store=st)
+    tb._pgrad(m.n.bias, store=st)
+    assert st and tb.grad_stored == [True, False, True, True]
+    tb._pgrad(m.n.weight)
+    assert not tb._fw
+    written = {(o, n) for (_, o, n) in tb.grad_writes}
+    stored = {(o, n) for (_, o, n), s_ in zip(tb.grad_writes, tb.grad_stored) if s_}
+    assert stored < written
+    # begin_window: a stale range of another plan is zeroed, stored ranges are left for the plan to overwrite
+    flat.grad.fill_(3.0)
+    oq, ok_ = flat.offset[id(m.to_q.weight)], flat.offset[id(m.to_k.weight)]
+    flat.dirty = {(ok_, 64), (oq, 3 * 64)}                              # an earlier plan wrote K's gradient on its own, and the fused range
+    flat.begin_window(stored)
+    assert flat.dirty == {(oq, 3 * 64)}                                 # still to be overwritten by this plan's store
+    assert float(flat.grad[ok_:ok_ + 64].abs().max()) == 0.0           # zeroed (redundantly: the fused store covers it)
+    assert float(flat.grad[oq:oq + 64].min()) == 3.0                    # not touched: the plan stores it
+    flat.zero_grad()
+    assert not flat.dirty and float(flat.grad.abs().max()) == 0.0
 
 
 def _bench(args, env_extra, timeout=240):
