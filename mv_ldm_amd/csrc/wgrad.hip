@@ -447,6 +447,14 @@ int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits) {
     return MVLDM_OK;
 }
 
+// One split of a Linear whose gradient is to be WRITTEN (accumulate 0: the first write of a store-first window plan, train.py): the slab
+// [n][tap * ctot + c] of the only split IS the PyTorch layout [n_out][c_in] -- the kernel writes the gradient itself, no slab, no reduce
+// launch (the big 1280-wide FF / QKV projections: 52 MB slabs that were written, re-read and written again).  MVLDM_WGRAD_DIRECT=0: A/B knob.
+static inline bool wgrad_direct(const mvldm_wgrad_desc& d, const WgradParams& p, int splits) {
+    static const int on = getenv("MVLDM_WGRAD_DIRECT") ? atoi(getenv("MVLDM_WGRAD_DIRECT")) : 1;
+    return on && splits == 1 && p.taps == 1 && d.c_in == p.ctot && (d.accumulate & 1) == 0;
+}
+
 static inline int ilog2_exact(int v) {       // log2 of a power of two, -1 otherwise
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -490,6 +498,8 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
     p.n_tiles = tiles;
     p.n_splits = splits;
     p.xcd_map = kWgXcd;
+    const bool direct = wgrad_direct(d, p, splits);
+    if (direct) p.ws = d.grad;
     const dim3 grid(wg_grid(tiles, splits));
     static std::atomic<uint64_t> done_b{0}, done_h{0}, done_b32{0}, done_h32{0}, done_b48{0}, done_h48{0};
     rc = dispatch_dtype(d.act_dtype, [&](auto t) {
@@ -515,6 +525,7 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
         }
     });
     if (rc) return rc;
+    if (direct) return MVLDM_OK;
     const size_t total = (size_t)d.n_out * d.c_in * p.taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, d.workspace, d.grad, d.n_out,
                        d.c_in, p.ctot, p.taps, splits, d.accumulate);
@@ -551,6 +562,8 @@ int wgrad_run(const mvldm_wgrad_desc& d0, hipStream_t s) {
     p.n_tiles = p.tiles_n * p.taps * p.tiles_c;
     p.n_splits = splits;
     p.xcd_map = kWgXcd;
+    const bool direct = wgrad_direct(d, p, splits);
+    if (direct) p.ws = d.grad;
     const dim3 grid(wg_grid(p.n_tiles, splits));
     rc = dispatch_dtype(d.act_dtype, [&](auto t) {
         using T = decltype(t);
@@ -558,6 +571,7 @@ int wgrad_run(const mvldm_wgrad_desc& d0, hipStream_t s) {
         return check_launch();
     });
     if (rc) return rc;
+    if (direct) return MVLDM_OK;
     const size_t total = (size_t)d.n_out * d.c_in * p.taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, d.workspace, d.grad, d.n_out,
                        d.c_in, p.ctot, p.taps, splits, d.accumulate);

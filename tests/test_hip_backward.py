@@ -417,6 +417,38 @@ def test_wide_weight_gradient_form(ops, case, dtype):
             ops.conv_wgrad(xa, dyd, torch.zeros(co, 2 * ci, device="cuda"), ksize=1, x2=xa, form=2)       # a skip-concat shortcut
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("form", [1, 2], ids=["small", "wide"])
+def test_single_split_linear_weight_gradient_is_written_in_place(ops, dtype, form):
+    """a Linear weight gradient that needs ONE split and is to be written (accumulate = 0: the first write of a store-first window plan)
+    skips the slab and the reduce launch -- the kernel writes `grad` itself (wgrad.hip wgrad_direct).  Ragged in both directions
+    (n_out, c_in not multiples of the tiles), into a poisoned buffer (every element must be written), bit-identical to the slab +
+    reduce path (accumulate = 1 onto zeros), and the accumulating call still accumulates."""
+    rows, c, n = 100, 328, 456
+    x, w = rnd((rows, c), 301, dtype), rnd((n, c), 302, torch.float32, 1 / math.sqrt(c))
+    wd = w.to(dtype).double().requires_grad_()
+    y = x.double() @ wd.t()
+    dy = rnd((rows, n), 303, dtype)
+    gw, = torch.autograd.grad(y, (wd,), dy.double())
+    xg, dyd = x.to(dtype).cuda().view(rows, 1, 1, c), dy.to(dtype).cuda()
+    direct = torch.full((n, c), 7.0, device="cuda")
+    ops.conv_wgrad(xg, dyd, direct, ksize=1, form=form)                       # rows < 256: one split
+    assert relerr(direct, gw) < TOL[dtype]
+    via_reduce = torch.zeros(n, c, device="cuda")
+    ops.conv_wgrad(xg, dyd, via_reduce, ksize=1, form=form, accumulate=True)
+    assert torch.equal(direct, via_reduce)
+    ops.conv_wgrad(xg, dyd, direct, ksize=1, form=form, accumulate=True)
+    assert relerr(direct, 2 * gw) < TOL[dtype]
+    # a column slice of a fused projection's gradient (dy_ld > n_out) and a padded input (c_in < channels): the padded case keeps the reduce
+    half = torch.full((n // 2, c), 7.0, device="cuda")
+    ops.conv_wgrad(xg, dyd[:, :n // 2], half, ksize=1, form=form)
+    assert relerr(half, gw[:n // 2]) < TOL[dtype]
+    if form == 1:
+        cut = torch.full((n, c - 8), 7.0, device="cuda")
+        ops.conv_wgrad(xg, dyd, cut, ksize=1, c_in=c - 8, form=form)
+        assert relerr(cut, gw[:, :c - 8]) < TOL[dtype]
+
+
 BIG_ATTN = [("d40_3d_5120_4096", 8, 40, [5120, 4096]), ("d64_sd_1024x16", 5, 64, [1024] * 16)]
 
 
