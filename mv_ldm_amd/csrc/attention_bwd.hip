@@ -58,8 +58,11 @@ constexpr int bwd_v_pitch(int dv) {
     return bytes / 2;
 }
 
+// register budget: the d = 40 heads (DP = 48: 75 % of the attention time of the multi-view blocks) in MODE 1 came out at 198 VGPRs + 64
+// AGPRs = 6 over the 256 that let a second wave share the SIMD -- and a lone wave issues its VALU at half rate (attention.hip); asking for
+// two waves makes hipcc fit them (kernel_resources.json: no scratch)
 template <typename T, int DP, int MODE>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attention_bwd_kernel(const AttnBwdParams p) {
     constexpr int EPC = 8;
     constexpr int DV = (DP + 31) / 32 * 32, NDB = DV / 32;
     constexpr int KP = DP + 8, VP = bwd_v_pitch(DV);     // row pitches (elements): row-read layout / transpose-read layout

@@ -538,6 +538,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmParams p)
         cur ^= 1;
     }
 
+    // 16-bit problems that cannot take the lean loop (conv_in of the UNet and of the VAE encoder: 3 / 11 input channels) still write
+    // 16-byte rows through the LDS-staged epilogue: the per-element form stores 2-byte values 64 B per row and instruction -- the VAE's
+    // conv_in at 32 images of 256 x 256 (537 MB of output, 14 GFLOP) took 2.3 ms of a 68 ms training step, 0.23 TB/s
+    if constexpr (sizeof(T) == 2) {
+        if (p.stage_epi) {
+            igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
+            return;
+        }
+    }
     igemm_epilogue<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, hi, l31);
 }
 
@@ -1374,7 +1383,8 @@ template <typename KernT> static int launch_kernel(KernT kern, std::atomic<uint6
 
 template <typename T, int BM, int BN, int WM, int WN> static int launch_sync(const IgemmParams& p, hipStream_t s) {
     static std::atomic<uint64_t> done{0};
-    return launch_kernel(igemm_kernel<T, BM, BN, WM, WN>, done, 2 * (BM + BN) * Mma<T>::PITCH,
+    constexpr int ring = 2 * (BM + BN) * Mma<T>::PITCH, park = WM * WN * 32 * (park_blocks(BN / WN / 32) * 32 + 4) * 4;
+    return launch_kernel(igemm_kernel<T, BM, BN, WM, WN>, done, (sizeof(T) == 2 && park > ring) ? park : ring,
                          8 * p.sub_m * p.sub_n * p.splitk, WM * WN * 64, p, s);
 }
 
@@ -1501,6 +1511,10 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
             // (tiles 16 / 17 -- 128x64 with 5 slots, 64x64 with 6 -- were built and measured SLOWER than their 2-slot forms on every
             //  one-scene shape (tools/skinny_probe.py: 25.2 / 30.2 us against 22.0 / 21.8 on the 4x4-level conv): several 2-slot
             //  workgroups per CU already overlap each other's round trips; not instantiated)
+            // (GEGLU pairs a value block with the gate block 32 columns on INSIDE a wave's tile: a 32-column wave tile cannot -- refused,
+            //  never remapped.  The first build let it through; the epilogue then read the neighbouring wave's parked block, which is the
+            //  right one whenever that wave had already parked it: correct in most runs, different between eager and graph replay.)
+            if (p.epilogue == MVLDM_EPI_GEGLU) return set_error(MVLDM_ERR_UNSUPPORTED, "igemm: tile 18 does not take the GEGLU epilogue");
             if constexpr (sizeof(T) == 2) {
                 if (p.use_bl && !p.upsample) return launch_bl_deep<T, 192, 128, 2, 4, 4>(p, s);
             }
@@ -1638,7 +1652,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
         p.splitk = cdiv(p.k_tiles, p.k_tiles_per_split);  // drop empty splits
     }
     // LDS-staged epilogue: 16-byte rows need 8-column alignment of the 16-bit output (or a split-K slab)
-    p.stage_epi = p.use_bl && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
+    p.stage_epi = d.act_dtype != MVLDM_F32 && !kEnvNoStage && (p.splitk > 1 || (!p.dst_f32 && p.n_dst % 8 == 0 && p.dst_ld % 8 == 0));
     if (tile >= 9 && tile <= 10 && (!p.stage_epi || (tile == 10 && d.epilogue == MVLDM_EPI_GEGLU))) tile = 7;   // no per-element epilogue there; odd TN cannot pair GEGLU columns
     if (tile == 11 && !(p.use_bl && p.stage_epi && p.splitk == 1 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample &&
                         d.h_out == d.h_in && d.w_out == d.w_in && halo_rows_for(d.w_in) <= 384 &&

@@ -529,9 +529,10 @@ def _igemm_signature(d) -> tuple:
 
 _SMALL_ROWS = int(os.environ.get("MVLDM_TUNE_SMALL_ROWS", "64"))       # launches below this many output rows keep the rules
 _SPLITS = (0, 1, 2, 4, 8, 16, 32)
-# tiles tried on small launches: the 1 / 2 / 4-wave tiles and tile 18 (192x128, 4-slot ring: up to 192 rows read every weight byte once; wins
-# the wide GEGLU projections at 8x8).  The tall 2-slot tiles 6 / 7 (256x64, 256x128) were tried and never picked (tools/skinny_probe.py).
-_SMALL_TILES = tuple(int(t) for t in os.environ.get("MVLDM_TUNE_SMALL_TILES", "0,1,2,3,4,5,18").split(","))
+# tiles tried on small launches: the 1 / 2 / 4-wave tiles.  The tall 2-slot tiles 6 / 7 (256x64, 256x128) and the deep-ring tile 18 (192x128, 4 slots:
+# up to 192 rows read every weight byte once) were tried and never win a shape they compute correctly (tools/skinny_probe.py; tile 18's one
+# apparent win, the 8x8 GEGLU projection, was an epilogue it cannot do -- refused now); MVLDM_TUNE_SMALL_TILES=0,1,2,3,4,5,18 puts it back.
+_SMALL_TILES = tuple(int(t) for t in os.environ.get("MVLDM_TUNE_SMALL_TILES", "0,1,2,3,4,5").split(","))
 
 
 def _unpack_choice(v):
@@ -571,6 +572,8 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
         small = rows < min_rows
         key = _igemm_signature(d)
         best = _TUNE_CACHE.get(key)
+        if best is not None and _unpack_choice(best)[0] not in (set(_TUNE_TILES) | set(_SMALL_TILES)):
+            best = None          # an entry of an older build / another candidate set (a tile this build no longer offers): time it again
         if best is None:
             trial = L.Op()
             C.memmove(C.byref(trial), C.byref(op), C.sizeof(L.Op))

@@ -180,7 +180,7 @@ def test_geglu(ops, dtype, rows, c):
         assert y.shape == (rows, 4 * c)
         close(y.float().cpu().double(), ref, dtype, f"geglu splitk{sk}")
     if dtype != torch.float32:   # the 8-wave tiles (staged epilogue only) with the GEGLU column pairing
-        for tile in (1, 7, 8, 9, 18):
+        for tile in (1, 7, 8, 9):
             y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=tile)
             close(y.float().cpu().double(), ref, dtype, f"geglu tile{tile}")
 
@@ -217,6 +217,10 @@ def test_deep_ring_tile_for_small_launches(ops, dtype):
     for sk in (1, 4):
         y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), residual=res.to(dtype).cuda(), tile=18, splitk=sk)
         close(y.float().cpu().double(), F.linear(x.double(), wt.double(), b.double()) + res.double(), dtype, f"linear+res tile18/splitk{sk}")
+    # GEGLU pairs value and gate blocks inside a wave's tile; tile 18's waves own 32 columns: refused, not remapped, not approximated
+    wg = rnd((8 * 64, 64), 82, dtype, 1 / 8.0)
+    with pytest.raises(RuntimeError, match="GEGLU"):
+        ops.linear(rnd((300, 64), 83, dtype).to(dtype).cuda(), ops.pack_weight(wg.cuda(), dtype, geglu=True), None, epilogue=2, tile=18)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
