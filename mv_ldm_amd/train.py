@@ -125,6 +125,11 @@ class TrainBuilder(Builder):
         self.store_first = bool(store_first)
         self.grad_stored: List[bool] = []                      # per entry of grad_writes: was it emitted as a store
         self._fw = False
+        # the weight gradient, the data gradient and the bias sums of ONE layer only share their input dY: emitted as three parallel
+        # lanes (MVLDM_OP_PAR_*: side streams) they overlap each other's tails and launch gaps (MVLDM_TRAIN_PAR=0: one after the other)
+        self.par_bwd = os.environ.get("MVLDM_TRAIN_PAR", "0") != "0"
+        self.par_rows = int(os.environ.get("MVLDM_TRAIN_PAR_ROWS", "0"))      # > 0: lanes only for layers with at most this many rows
+        self._wws_lane: Dict[int, torch.Tensor] = {}
         self.tape: List[Callable[[], None]] = []
         self.grads: Dict[tuple, torch.Tensor] = {}
         self.repack: List[Callable[[], None]] = []
@@ -205,12 +210,40 @@ class TrainBuilder(Builder):
         op.u.fill.dst, op.u.fill.bytes = ptr(t), t.numel() * t.element_size()
         self._emit(op, name, 0.0, t.numel() * t.element_size(), (t,))
 
+    class _NoLanes:
+        def __enter__(self):
+            return self
+
+        def lane(self):
+            pass
+
+        def __exit__(self, *a):
+            return False
+
+    def _bwd_lanes(self, rows: int = 0):
+        on = self.par_bwd and (self.par_rows <= 0 or rows <= self.par_rows)
+        return self.parallel() if on else TrainBuilder._NoLanes()
+
+    def _tws(self) -> torch.Tensor:
+        """scratch of the training ops (weight-gradient slabs, column-sum / norm partials): the plan's big one on the main lane, a
+        64 MB one per side lane (the lanes of a parallel group run at the same time)"""
+        lane = getattr(self, "_lane", 0)
+        if not lane:
+            return self._wws
+        ws = self._wws_lane.get(lane)
+        if ws is None:
+            ws = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)
+            self._wws_lane[lane] = ws
+            self.keep.append(ws)
+        return ws
+
     def _colsum(self, x2d, n, dst, ld_dst, rows_per_seg, per_seg, accumulate, name):
         rows = x2d.shape[0]
         op = L.Op()
         op.kind = L.OP_COLSUM
         c = op.u.colsum
-        c.x, c.dst, c.workspace, c.workspace_bytes = ptr(x2d), ptr(dst), ptr(self._wws), self._wws.numel()
+        tws = self._tws()
+        c.x, c.dst, c.workspace, c.workspace_bytes = ptr(x2d), ptr(dst), ptr(tws), tws.numel()
         c.n_seg, c.rows_per_seg, c.n, c.ld, c.ld_dst = rows // rows_per_seg, rows_per_seg, n, x2d.stride(0), ld_dst
         c.per_seg, c.accumulate, c.dtype = int(per_seg), int(accumulate), dt(x2d)
         self._emit(op, name, 0.0, x2d.numel() * x2d.element_size(), (x2d, dst))
@@ -222,6 +255,7 @@ class TrainBuilder(Builder):
         op.kind = L.OP_WGRAD
         d = op.u.wgrad
         d.src0, d.src1, d.dy, d.grad = ptr(x), ptr(x2), ptr(dy2d), ptr(grad)
+        assert not getattr(self, "_lane", 0), "weight gradients run on the main lane (they own the big slab workspace)"
         d.workspace, d.workspace_bytes = ptr(self._wws), self._wws.numel()
         d.c0, d.c1, d.c_in = c0, 0 if x2 is None else x2.shape[-1], c_in
         d.n_img, d.h_in, d.w_in, d.h_out, d.w_out = n, h, w, geom["ho"], geom["wo"]
@@ -315,13 +349,8 @@ class TrainBuilder(Builder):
             if dy is None:
                 return
             dy = self._as_act(dy, name + ".dy_cast")
-            with self.scope("bwd/" + name):
-                off = 0
-                for i, w in enumerate(weights):
-                    if biases:
-                        for p in biases[i]:
-                            self._colsum(dy[:, off:off + n_i[i]], n_i[i], self._pgrad(p), n_i[i], rows, False, not self._fw, "dbias")
-                    off += n_i[i]
+            with self.scope("bwd/" + name), self._bwd_lanes(rows) as par:
+                par.lane()          # ---- the weight gradient(s): main lane
                 geom = dict(ho=1, wo=1, ksize=1, stride=1, pad=0, upsample=False)
                 if len(weights) == 1 or self.flat.contiguous(list(weights)):
                     self._wgrad(x.view(rows, 1, 1, c), None, dy, sum(n_i), self._pgrad(weights[0], through=weights[-1]), geom, c, "wgrad")
@@ -331,11 +360,20 @@ class TrainBuilder(Builder):
                         self._wgrad(x.view(rows, 1, 1, c), None, dy[:, off:off + n_i[i]], n_i[i], self._pgrad(w), geom, c, f"wgrad.{i}")
                         off += n_i[i]
                 if x_grad:
+                    par.lane()      # ---- the data gradient
                     cur = self.pop_grad(x)
                     dx = Builder.linear(self, dy, pts[0], None, residual=cur, name="dgrad")
                     self.grads[_key(x)] = dx
-                if residual is not None:
-                    self.add_grad(residual, dy)
+                if biases or residual is not None:
+                    par.lane()      # ---- bias sums, the residual branch's share of dY
+                    off = 0
+                    for i, w in enumerate(weights):
+                        if biases:
+                            for p in biases[i]:
+                                self._colsum(dy[:, off:off + n_i[i]], n_i[i], self._pgrad(p), n_i[i], rows, False, not self._fw, "dbias")
+                        off += n_i[i]
+                    if residual is not None:
+                        self.add_grad(residual, dy)
         self.tape.append(backward)
         return y
 
@@ -365,13 +403,19 @@ class TrainBuilder(Builder):
                 return
             dy = self._as_act(dy, name + ".dy_cast")
             dy2d = dy.view(n * ho * wo, dy.shape[-1])
-            with self.scope("bwd/" + name):
-                if bias_p is not None:
-                    self._colsum(dy2d, co, self._pgrad(bias_p), co, n * ho * wo, False, not self._fw, "dbias")
-                if row_bias is not None:      # gradient of the per-image time-embedding row: column sums per image
-                    self._colsum(dy2d, co, row_bias[1], row_bias[1].stride(0), ho * wo, True, False, "d_temb_row")
+            with self.scope("bwd/" + name), self._bwd_lanes(n * ho * wo) as par:
+                par.lane()          # ---- the weight gradient: main lane
                 self._wgrad(x, x2, dy2d, co, self._pgrad(weight), geom, c_in, "wgrad")
+                if bias_p is not None or row_bias is not None or residual is not None:
+                    par.lane()      # ---- bias / time-embedding-row sums, the residual branch's share of dY
+                    if bias_p is not None:
+                        self._colsum(dy2d, co, self._pgrad(bias_p), co, n * ho * wo, False, not self._fw, "dbias")
+                    if row_bias is not None:      # gradient of the per-image time-embedding row: column sums per image
+                        self._colsum(dy2d, co, row_bias[1], row_bias[1].stride(0), ho * wo, True, False, "d_temb_row")
+                    if residual is not None:
+                        self.add_grad(residual, dy)
                 if x_grad:
+                    par.lane()      # ---- the data gradient
                     src = dy
                     if stride == 2:          # zero insertion turns the strided conv's data gradient into a stride-1 conv
                         z = self.empty(n, 2 * ho, 2 * wo, dy.shape[-1])
@@ -390,8 +434,6 @@ class TrainBuilder(Builder):
                             cur = self.pop_grad(xs)
                             dx = Builder.conv(self, src, pt, None, residual=cur, name="dgrad")
                             self.grads[_key(xs)] = dx
-                if residual is not None:
-                    self.add_grad(residual, dy)
         self.tape.append(backward)
         return y
 
@@ -1309,6 +1351,7 @@ class MVLDMTrainer:
         RCCL's stream while the remaining (earlier-layer) backward kernels keep the compute stream busy"""
         n_ops = len(tp.plan)
         cuts = bucket_cut_points(tp.grad_writes, self.opt.buckets, n_ops)
+        cuts = [(k, par_safe_cut(tp.plan.ops, end)) for k, end in cuts]       # never inside a parallel group (plan_run_range refuses that)
         done = 0
         for k, end in cuts:
             if end > done:
@@ -1380,6 +1423,23 @@ def bucket_cut_points(grad_writes: Sequence[Tuple[int, int, int]], buckets: Sequ
                 last[k] = max(last[k], op_idx + 1)
             k += 1
     return sorted(((k, min(e, n_ops)) for k, e in last.items()), key=lambda t: (t[1], -t[0]))
+
+
+def par_safe_cut(ops, end: int) -> int:
+    """the first index >= `end` that does not lie inside a parallel group (PAR_BEGIN .. PAR_END) of the plan's op list"""
+    open_at = None
+    for i in range(end):
+        k = ops[i].kind
+        if k == L.OP_PAR_BEGIN:
+            open_at = i
+        elif k == L.OP_PAR_END:
+            open_at = None
+    if open_at is None:
+        return end
+    i = end
+    while ops[i].kind != L.OP_PAR_END:
+        i += 1
+    return i + 1
 
 
 def _flat_padded(denoiser, world: int) -> FlatParams:

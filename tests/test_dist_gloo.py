@@ -390,3 +390,14 @@ def test_tile_choices_are_rank_zeros_on_every_rank_and_survive_a_file(tmp_path):
     finally:
         P._TUNE_CACHE.clear(); P._WGRAD_CACHE.clear()
         P._TUNE_CACHE.update(keep[0]); P._WGRAD_CACHE.update(keep[1])
+
+
+def test_bucket_cuts_never_land_inside_a_parallel_group():
+    """the backward plan emits the weight gradient, the data gradient and the bias sums of a layer as parallel lanes; the segments
+    between two reduce-scatters must not cut such a group (mvldm_plan_run_range refuses a range that starts or ends inside one)"""
+    from types import SimpleNamespace as NS
+    from mv_ldm_amd import _lib as L
+    from mv_ldm_amd.train import par_safe_cut
+    K = [1, L.OP_PAR_BEGIN, 14, L.OP_PAR_NEXT, 1, L.OP_PAR_NEXT, 18, L.OP_PAR_END, 2, L.OP_PAR_BEGIN, 14, L.OP_PAR_END, 3]
+    ops = [NS(kind=k) for k in K]
+    assert [par_safe_cut(ops, e) for e in range(len(K) + 1)] == [0, 1, 8, 8, 8, 8, 8, 8, 8, 9, 12, 12, 12, 13]
