@@ -83,14 +83,22 @@ template <> struct WgMma<f16_t> {
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
+constexpr int wg_tr_pitch(int cols) {        // elements (16-bit)
+    int bytes = 2 * cols;
+    while (bytes % 256 != 64 && bytes % 256 != 192) bytes += 32;
+    return bytes / 2;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     constexpr bool F32 = std::is_same<T, float>::value;
     constexpr int EPC = Elt<T>::EPC;
-    // row pitches (elements): 16-bit tiles keep the 4 pixel rows of a transpose-read group on disjoint banks (+16 elements
-    // = 32 bytes, the pitch rule of the attention V tile); fp32 rows are read as scalars (lanes = consecutive columns)
-    constexpr int PD = F32 ? WG_BN + 4 : WG_BN + 16;
-    constexpr int PX = F32 ? WG_BC + 4 : WG_BC + 16;
+    // row pitches (elements): a transpose-read half-wave touches 4 pixel rows x two 32-byte column pieces, conflict-free when the
+    // pitch in bytes is 64 or 192 (mod 256) -- the rule attention.hip's v_pitch() measured.  (Rounds 2 - 3 used "+32 bytes" here:
+    // 288 / 160 bytes, SQ_LDS_BANK_CONFLICT = 33 % of the LDS cycles of this kernel, tools/pmc_kernels.sh over tools/wgrad_bench.py.)
+    // fp32 rows are read as scalars (lanes = consecutive columns).
+    constexpr int PD = F32 ? WG_BN + 4 : wg_tr_pitch(WG_BN);
+    constexpr int PX = F32 ? WG_BC + 4 : wg_tr_pitch(WG_BC);
     constexpr int D_CH = WG_BN / EPC, X_CH = WG_BC / EPC;          // 16-byte chunks per tile row
     constexpr int D_IT = WG_BP * D_CH / 256, X_IT = WG_BP * X_CH / 256;
     __shared__ __attribute__((aligned(16))) T s_d[WG_BP * PD];
