@@ -82,7 +82,10 @@ typedef struct mvldm_igemm_desc {
     int32_t splitk;     /* >= 1; 0 = let the library choose (needs workspace) */
     int32_t tile;       /* 0 = auto; else force a tile config (tests / tuning / plan-time selection): 1..11 igemm.hip tiles,
                            12 = persistent Linear with the epilogue pipelined under the next tile (linear_pp.hip: 1x1, one or two
-                           sources, K >= 320 a multiple of 64, 16-bit in and out; any other problem is an error, not a fallback) */
+                           sources, K >= 320 a multiple of 64, 16-bit in and out; any other problem is an error, not a fallback),
+                           13 = persistent wide Linear (linear_pw.hip), 14 = weight-stationary Linear for K = 320 (linear_ws.hip),
+                           18 = 192 x 128 tile with a 4-slot ring (igemm.hip; 1x1 / 3x3, no upsampling forms, no GEGLU: refused).
+                           Bits 0-5 = the tile id; bits 8-11 / 12 = tuning overrides (XCD grid, register-prefetch loop) */
     int32_t k_order;    /* K order of the packed weight: 0 = (tap, channel); 1 = (64-channel block, tap, channel) */
     int32_t dst_ld;     /* row stride of dst in elements; 0 = n_dst (dense).  > n_dst writes into a wider buffer */
     float out_scale;
