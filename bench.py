@@ -164,9 +164,14 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
     window = os.environ.get("MVLDM_TRAIN_WINDOW", "1") != "0"
     ch = dict(index=1, unconditional=False)
 
+    # the frozen VAE encoder of the NEXT window runs on a side stream under this window's backward (same draws, same order, same
+    # result; MVLDM_TRAIN_PREFETCH=0: encode at the start of the window's own call, A/B)
+    prefetch = window and os.environ.get("MVLDM_TRAIN_PREFETCH", "1") != "0"
+    win_b, win_c = [batch] * acc, [ch] * acc
+
     def opt_step():
         if window:
-            return list(tr.training_window([batch] * acc, [ch] * acc))
+            return list(tr.training_window(win_b, win_c, prefetch=(win_b, win_c) if prefetch else None))
         return [tr.training_step(batch, **ch) for _ in range(acc)]
     for _ in range(args.warmup):
         opt_step()
@@ -184,6 +189,8 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
            "config": {"workload": f"configs[3]: optimizer step = {acc} micro-batches of {b} scenes x (1 ctx + 3 tgt) @ {args.res}x{args.res} per GPU: VAE "
                                   "encode, add_noise, UNet fwd+bwd (SD-2.1 topology + 9 multi-view blocks), MSE, clip 0.1, AdamW (fp32 master weights)",
                       "accumulation": "one plan per window (both micro-batches in one forward / backward)" if window else "one plan run per micro-batch",
+                      "vae_encode": "the next window's encoder call overlaps this window's backward (side stream; every step still encodes its own "
+                                    "32 views)" if prefetch else "at the start of the window's own call",
                       "draws": "FIXED shape: every micro-batch keeps its context view and its conditioning (index=1, unconditional=False), i.e. one recorded "
                                "plan serves every window.  The reference draws the context count and a 10 % CFG drop per micro-batch "
                                "(diffusion_wrapper.py:336,381): a randomised run meets up to S^2 window shapes, each recorded (and tuned) on first "

@@ -587,3 +587,34 @@ def test_bf16_gradients_against_the_f32_hip_path_at_full_width():
     print(r)
     assert r["grad_rel_l2"] < 6e-2 and abs(r["grad_norm_ratio"] - 1.0) < 5e-2 and r["loss_rel"] < 2e-2, r
     assert r["worst_large_param_rel_l2"] < 0.25, r
+
+
+def test_encoding_the_next_window_ahead_changes_nothing_but_the_time(golden):
+    """`training_window(..., prefetch=(next batches, next choices))`: the next window's host part + VAE encode run on a side stream
+    under this window's backward.  Three windows with the reference's own random draws (context count, pose coin, CFG drop, posterior,
+    noise, timesteps all drawn, nothing given): losses, gradient norms and weights bit-identical to the run that encodes at the start
+    of each call; a window prepared for other batches than the ones that arrive is re-encoded, not used."""
+    from mv_ldm_amd.train import OptimizerCfg
+    g = golden("g9_training_step")
+    b0, b1 = g9_case(g, 0)[0], g9_case(g, 2)[0]
+    seq = [[b0, b1], [b1, b1], [b0, b0]]
+    got = []
+    for ahead in (False, True):
+        tr = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3))
+        torch.manual_seed(11)
+        np.random.seed(11)
+        out = []
+        for i, bts in enumerate(seq):
+            nxt = (seq[i + 1], None) if ahead and i + 1 < len(seq) else None
+            losses = tr.training_window(bts, prefetch=nxt)
+            out.append(([float(x) for x in losses], float(tr.opt.norm[0])))
+        torch.cuda.synchronize()
+        got.append((out, tr.flat.flat.clone()))
+    assert got[0][0] == got[1][0], (got[0][0], got[1][0])
+    assert torch.equal(got[0][1], got[1][1])
+    # prepared for [b0, b0] but [b1, b1] arrives: encoded again for the batches that came (no stale latents)
+    tr = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3))
+    ch = [hip_choices(g9_case(g, 2)[1])] * 2
+    want = [float(x) for x in build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3)).training_window([b1, b1], ch)]
+    tr._start_prefetch([b0, b0], None)
+    assert [float(x) for x in tr.training_window([b1, b1], ch)] == want
