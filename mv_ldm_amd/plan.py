@@ -529,6 +529,11 @@ def _igemm_signature(d) -> tuple:
 
 _SMALL_ROWS = int(os.environ.get("MVLDM_TUNE_SMALL_ROWS", "64"))       # launches below this many output rows keep the rules
 _SPLITS = (0, 1, 2, 4, 8, 16, 32)
+# launches of a few thousand to a few ten thousand rows (a training window's 16x16 / 8x8 levels, 4 - 16 scenes of sampling, the 8x8 / 4x4 levels
+# at 64 scenes): every tile x a few split-K counts -- the rule's split (fill ~512 workgroups) is one guess there too: training 63.2 -> 61.8 ms per
+# optimizer step, b = 4 11.24 -> 10.69 ms per DDIM step (same-box A/Bs); 0 = tile only, at the rule's split, as before
+_MID_ROWS = int(os.environ.get("MVLDM_TUNE_MID_ROWS", "40000"))
+_MID_SPLITS = (0, 1, 2, 3, 4, 6, 8)
 # tiles tried on small launches: the 1 / 2 / 4-wave tiles.  The tall 2-slot tiles 6 / 7 (256x64, 256x128) and the deep-ring tile 18 (192x128, 4 slots:
 # up to 192 rows read every weight byte once) were tried and never win a shape they compute correctly (tools/skinny_probe.py; tile 18's one
 # apparent win, the 8x8 GEGLU projection, was an epilogue it cannot do -- refused now); MVLDM_TUNE_SMALL_TILES=0,1,2,3,4,5,18 puts it back.
@@ -580,7 +585,8 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
             # small launches: the 4-wave / 2-wave / 1-wave tiles x split counts (only where the op carries a split-K workspace and lets
             # the library choose); large launches: every tile at the descriptor's own split
             can_split = small and bool(d.workspace) and d.splitk == 0
-            cands = [(t, None) for t in _TUNE_TILES] if not small else \
+            mid = (not small) and rows < _MID_ROWS and bool(d.workspace) and d.splitk == 0
+            cands = [(t, sk) for t in _TUNE_TILES for sk in _MID_SPLITS] if mid else [(t, None) for t in _TUNE_TILES] if not small else \
                     [(t, sk) for t in _SMALL_TILES if t in _TUNE_TILES or not os.environ.get("MVLDM_TUNE_TILES") for sk in (_SPLITS if can_split else (None,))]
             n_it = iters if not small else 3 * iters
             results = []
