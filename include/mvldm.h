@@ -289,7 +289,8 @@ typedef struct mvldm_wgrad_desc {
     int32_t act_dtype;
     int32_t accumulate;                        /* bit 0: 0 grad = ..., 1 grad += ... (accumulation over micro-batches);
                                                 * bits 8-9: kernel form, 0 = the library's rule, 1 = register-staged [128 n x 64 c] tile,
-                                                * 2 = wide LDS-DMA [320 n x 128 c] tile (refused where it does not apply) */
+                                                * 2 = wide LDS-DMA [320 n x 128 c] tile (refused where it does not apply);
+                                                * bits 10-12: workgroup target of the pixel split, 0 = the library's, else 64 << code */
 } mvldm_wgrad_desc;
 int mvldm_igemm_wgrad(const mvldm_wgrad_desc* d, mvldm_stream_t stream);
 

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static inline int cdiv_(int a, int b) { return (a + b - 1) / b; }
 
-int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits) {
+int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits, int tcode = 0) {
     const int epc = d.act_dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(d.src0 && d.dy && d.grad, "wgrad: null pointer");
     MVLDM_REQUIRE(d.ksize == 1 || d.ksize == 3, "wgrad: ksize %d", d.ksize);
@@ -445,7 +445,9 @@ int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits) {
     const int tiles = p.tiles_n * p.taps * p.tiles_c;
     const int blocks = cdiv_(p.M, WG_BP);
     static const int kTarget = getenv("MVLDM_WGRAD_TARGET") ? atoi(getenv("MVLDM_WGRAD_TARGET")) : 512;   // workgroups aimed at (512 / 1024 / 2048 / 4096: 303 / 300 / 300 / 292 training views/s)
-    splits = std::max(1, std::min(cdiv_(kTarget, tiles), std::max(1, blocks / 4)));
+    // (bits 10-12 of the caller's `accumulate` -- the host's per-problem choice, plan.autotune_wgrad -- name the target: 64 << code)
+    const int target = tcode ? (64 << tcode) : kTarget;
+    splits = std::max(1, std::min(cdiv_(target, tiles), std::max(1, blocks / 4)));
     const size_t slab = (size_t)d.n_out * p.kdim * sizeof(float);
     while (splits > 1 && (size_t)splits * slab > d.workspace_bytes) --splits;
     MVLDM_REQUIRE(d.workspace && (size_t)splits * slab <= d.workspace_bytes, "wgrad: workspace of %zu bytes too small (need >= %zu)",
@@ -482,7 +484,7 @@ static bool wgrad_wide_ok(const mvldm_wgrad_desc& d) {
     return xb < 0xFFFFFFF0ull;
 }
 
-static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
+static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s, int tcode = 0) {
     WgradDmaParams q;
     WgradParams& p = q.w;
     int splits = 1;
@@ -497,7 +499,8 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s) {
     static const int kBp = getenv("MVLDM_WGRAD_WIDE_BP") ? atoi(getenv("MVLDM_WGRAD_WIDE_BP")) : 64;      // 64: 2-slot ring (default), 32: 4-slot (measured 18 % slower)
     const int tiles = p.tiles_n * p.taps * p.tiles_c, blocks = cdiv_(p.M, 64);
     static const int kTarget = getenv("MVLDM_WGRAD_WIDE_TARGET") ? atoi(getenv("MVLDM_WGRAD_WIDE_TARGET")) : 256;      // one round of workgroups: half the slab traffic of two (512: 2324 us over tools/wgrad_bench.py, 256: 2190)
-    splits = std::max(1, std::min(kTarget / std::max(tiles, 1), std::max(1, blocks / 4)));
+    const int target = tcode ? (64 << tcode) : kTarget;
+    splits = std::max(1, std::min(target / std::max(tiles, 1), std::max(1, blocks / 4)));
     const size_t slab = (size_t)d.n_out * p.kdim * sizeof(float);
     while (splits > 1 && (size_t)splits * slab > d.workspace_bytes) --splits;
     MVLDM_REQUIRE((size_t)splits * slab <= d.workspace_bytes, "wgrad: workspace of %zu bytes too small (need >= %zu)", d.workspace_bytes, slab);
@@ -560,12 +563,13 @@ int wgrad_run(const mvldm_wgrad_desc& d0, hipStream_t s) {
     const int form = (d0.accumulate >> 8) & 3;
     MVLDM_REQUIRE(form != 2 || wgrad_wide_ok(d0), "wgrad: the wide form does not take this problem");
     const bool wide = wgrad_pick_wide(d0);
+    const int tcode = (d0.accumulate >> 10) & 7;      // split target chosen by the host (0: the library's)
     mvldm_wgrad_desc d = d0;
     d.accumulate &= 1;
-    if (wide) return wgrad_run_wide(d, s);
+    if (wide) return wgrad_run_wide(d, s, tcode);
     WgradParams p;
     int splits = 1;
-    int rc = wgrad_plan(d, p, splits);
+    int rc = wgrad_plan(d, p, splits, tcode);
     if (rc) return rc;
     p.n_tiles = p.tiles_n * p.taps * p.tiles_c;
     p.n_splits = splits;

@@ -616,6 +616,9 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
     return timed
 
 
+_WGRAD_TARGETS = tuple(int(t) for t in os.environ.get("MVLDM_TUNE_WGRAD_TARGETS", "0,1,2,3,4,5").split(","))      # 0 = library default, 64 << code
+
+
 def autotune_wgrad(ops, iters: int = 3) -> int:
     """plan-time choice between the two weight-gradient kernels (csrc/wgrad.hip: register-staged small tile / wide LDS-DMA tile)
     per problem signature: both are timed on the op's own buffers (scratch at this point; the gradient it writes is zeroed before
@@ -648,16 +651,20 @@ def autotune_wgrad(ops, iters: int = 3) -> int:
                 scratch[:need].zero_()       # the trials accumulate: no Inf / NaN left over from an earlier, larger problem
             trial.u.wgrad.grad = scratch.data_ptr()
             results = []
+            # form (bits 8-9) x workgroup target of the pixel split (bits 10-12: 0 = the library's 512 / 256, else 64 << code): fewer
+            # splits halve a small layer's slab traffic, more fill the chip on a long pixel range -- one value per problem
             for form in (1, 2):
-                trial.u.wgrad.accumulate = (d.accumulate & 1) | (form << 8)
-                if lib.mvldm_op_run(C.byref(trial), stream) != 0:      # the wide form does not take this problem
-                    continue
-                e0.record()
-                for _ in range(iters):
-                    lib.mvldm_op_run(C.byref(trial), stream)
-                e1.record()
-                e1.synchronize()
-                results.append((e0.elapsed_time(e1), form))
+                for tcode in _WGRAD_TARGETS:
+                    v = form + 4 * tcode
+                    trial.u.wgrad.accumulate = (d.accumulate & 1) | (v << 8)
+                    if lib.mvldm_op_run(C.byref(trial), stream) != 0:      # the wide form does not take this problem
+                        break
+                    e0.record()
+                    for _ in range(iters):
+                        lib.mvldm_op_run(C.byref(trial), stream)
+                    e1.record()
+                    e1.synchronize()
+                    results.append((e0.elapsed_time(e1), v))
             best = min(results)[1] if results else 0
             _WGRAD_CACHE[key] = best
             timed += 1
