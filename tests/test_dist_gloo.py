@@ -401,3 +401,45 @@ def test_bucket_cuts_never_land_inside_a_parallel_group():
     K = [1, L.OP_PAR_BEGIN, 14, L.OP_PAR_NEXT, 1, L.OP_PAR_NEXT, 18, L.OP_PAR_END, 2, L.OP_PAR_BEGIN, 14, L.OP_PAR_END, 3]
     ops = [NS(kind=k) for k in K]
     assert [par_safe_cut(ops, e) for e in range(len(K) + 1)] == [0, 1, 8, 8, 8, 8, 8, 8, 8, 9, 12, 12, 12, 13]
+
+
+def _harness_worker(rank, world, port, q):
+    from mv_ldm_amd import generate as G
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = G.merge_config(G.DEFAULT_CONFIG, {"test": {"sampling_mode": "anchored", "num_anchors_views": 4}, "seed": 7})
+    ex = [G.synthetic_example(0, 40, 64, 7)]
+    r = G.evaluate(cfg, ex, pipe=_StubPipeline(), rank=rank, world=world)
+    q.put((rank, r["sharded_calls"], r["views_per_rank"], {f: v.numpy().copy() for f, v in r["frames"][ex[0]["scene"][0]].items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_harness_shards_the_calls_of_one_scene_when_there_are_fewer_scenes_than_ranks():
+    """`generate.evaluate` with ONE 40-frame scene on two ranks (SURVEY.md §8e "within one 80-frame scene"): the anchors come from rank 0
+    (broadcast once), the independent groups are split over the ranks, together the ranks hold exactly the frames -- bit for bit -- of the
+    one-rank walk with the same seed, and the per-rank view counts add up"""
+    from mv_ldm_amd import generate as G
+    cfg = G.merge_config(G.DEFAULT_CONFIG, {"test": {"sampling_mode": "anchored", "num_anchors_views": 4}, "seed": 7})
+    ex = [G.synthetic_example(0, 40, 64, 7)]
+    one = G.evaluate(cfg, ex, pipe=_StubPipeline(), leaf_batch=1)
+    want = one["frames"][ex[0]["scene"][0]]
+    assert not one.get("sharded_calls") and len(want) == one["views"]
+    # the single-rank walk seeds scene i's noise with seed * 65537 + i: the sharded walk uses the same streams
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_harness_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(g[1] for g in got) and got[0][2] == got[1][2] and sum(got[0][2]) == len(want)
+    f0, f1 = got[0][3], got[1][3]
+    assert not (set(f0) & set(f1)) and set(f0) | set(f1) == set(want)
+    for fr in (f0, f1):
+        for f, im in fr.items():
+            assert torch.equal(torch.from_numpy(im), want[f].cpu()), f
