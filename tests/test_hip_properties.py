@@ -172,3 +172,44 @@ def test_plan_time_autotune_freezes_a_valid_tile(ops):
     for y, y2 in outs:
         assert torch.equal(y, y2)
         assert (y.float() - ref.float()).norm() / ref.float().norm() < 4e-3
+
+
+def test_every_candidate_the_tuner_may_freeze_reproduces_the_rules_result(ops):
+    """the plan-time tuner freezes whatever (tile, split-K) ran fastest: every candidate it may try must either REFUSE the problem or
+    compute it -- same result as the library's rule to rounding, and the same bits on a second run.  (Round 4: a new tile let the GEGLU
+    epilogue through that its wave tile cannot pair; it read a neighbouring wave's parked block, right in most runs, and won a timing.)
+    Problems: the epilogues and geometries the UNet carries, at the row counts the small / mid tuners see."""
+    from mv_ldm_amd import plan as P
+    dtype = torch.bfloat16
+    tiles = sorted(set(P._TUNE_TILES) | set(P._SMALL_TILES) | {18})
+    splits = sorted(set(s_ for s_ in P._SPLITS if s_ <= 8) | set(P._MID_SPLITS))
+    cases = [  # name, n_img, h, c_in, n_out, ksize, epilogue, residual, row_bias
+        ("geglu 320->2560", 9, 8, 320, 2560, 1, 2, False, False),
+        ("geglu 1280->10240 few rows", 9, 4, 1280, 10240, 1, 2, False, False),
+        ("linear 1280->1280 + residual", 9, 8, 1280, 1280, 1, 0, True, False),
+        ("conv3x3 1280->320 + temb row", 9, 8, 1280, 320, 3, 0, False, True),
+        ("conv3x3 320->320 + residual, 16x16", 10, 16, 320, 320, 3, 0, True, False),
+    ]
+    tried = refused = 0
+    for name, n, h, ci, co, k, epi, res, rb in cases:
+        x = _randn((n, h, h, ci), 500, dtype)
+        w = _randn((co, ci, k, k), 501, torch.float32, 1.0 / math.sqrt(ci * k * k))
+        pw = ops.pack_weight(w if k == 3 else w[:, :, 0, 0], dtype, geglu=epi == 2)
+        nd = co // 2 if epi == 2 else co
+        b = _randn((co,), 502, torch.float32, 0.1)
+        r = _randn((n, h, h, nd), 503, dtype) if res else None
+        rowb = _randn((n, nd), 504, torch.float32) if rb else None
+        kw = dict(residual=r, row_bias=rowb, epilogue=epi)
+        ref = ops.conv2d(x, pw, b, **kw).float()
+        for tile in tiles:
+            for sk in splits:
+                try:
+                    y = ops.conv2d(x, pw, b, tile=tile, splitk=sk, **kw)
+                except RuntimeError:
+                    refused += 1
+                    continue
+                tried += 1
+                e = float((y.float() - ref).norm() / ref.norm())
+                assert e < 6e-3, (name, tile, sk, e)
+                assert torch.equal(y, ops.conv2d(x, pw, b, tile=tile, splitk=sk, **kw)), (name, tile, sk, "second run differs")
+    assert tried > 200 and refused > 0, (tried, refused)
