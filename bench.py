@@ -352,7 +352,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--op-table", default=None, help="write the per-op profile (JSON) here")
-    ap.add_argument("--no-small-batch", action="store_true", help="skip the b in {1, 4, 16} latency lines")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the b in {1, 4, 16} latency lines (and the 128-scene line)")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the 128-scene throughput line")
     ap.add_argument("--no-parity", action="store_true", help="skip the 50-step f32-vs-bench-dtype drift measurement")
     ap.add_argument("--no-train-line", action="store_true", help="skip the short training-step measurement appended to the sampling line")
     ap.add_argument("--no-full-walk", action="store_true", help="skip the 2-sample run without the exact sharing (`exact_sharing.full_walk`)")
@@ -605,6 +606,25 @@ def main():
             small[f"b{sb}"] = {"views_per_s": round(sb * v_t / dt_s, 3), "sample_ms": round(dt_s * 1e3, 2),
                                "ddim_step_ms": round(step, 4), "two_roof": tr}
         out["small_batch"] = small
+        if b == 64 and not getattr(args, "no_large_batch", False):
+            # ---- and the other side of 64 scenes: the 288 GB of one GPU take more, and the tile quantisation of the deep levels eases off
+            # (`value` stays at 64 scenes per GPU, the configuration of every earlier round's line)
+            lb_ = 128
+            bt = synthetic_batch(lb_, v_c, v_t, args.res, 1234, dev, scene_ids=list(range(lb_)))
+            pipe.sample(bt)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                pipe.sample(bt)
+            torch.cuda.synchronize()
+            dt_s = (time.perf_counter() - t0) / 2
+            out["large_batch"] = {f"b{lb_}": {"views_per_s": round(lb_ * v_t / dt_s, 3), "sample_ms": round(dt_s * 1e3, 1), "samples": 2,
+                                            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}}
+            del bt
+            for key in [k_ for k_ in pipe._plans if k_[0] == lb_]:       # its activation arena goes back to the allocator
+                pipe._plans.pop(key)
+            torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_parity and args.dtype != "f32":
         # ---- stated tolerance of the benched dtype: 50 DDIM steps, one scene, from the same x_T / context latents, against

@@ -1,7 +1,8 @@
 #!/bin/bash
 # HBM-side traffic of one optimizer step of the training bench (step 5 of tools/r04_profiles.sh on its own)
 cd "$(dirname "$0")/.."
-export TMPDIR=/tmp MVLDM_TUNE_CACHE=/tmp/train_tune_cache.json
+# (MVLDM_TRAIN_PREFETCH=0: with the next window's VAE encode running under the backward its kernels would land inside the plan's dispatch range)
+export TMPDIR=/tmp MVLDM_TUNE_CACHE=/tmp/train_tune_cache.json MVLDM_TRAIN_PREFETCH=0
 O=gpurun_out/r04prof; mkdir -p $O
 P=/tmp/r04pmc; rm -rf $P
 python3 bench.py --train --steps 2 --warmup 1 --no-profile --no-parity > $O/train_pre.json 2> $O/train_pre.err     # fills the tune cache: the traced runs time no candidates
