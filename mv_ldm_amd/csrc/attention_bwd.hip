@@ -62,7 +62,7 @@ constexpr int bwd_v_pitch(int dv) {
 // AGPRs = 6 over the 256 that let a second wave share the SIMD -- and a lone wave issues its VALU at half rate (attention.hip); asking for
 // two waves makes hipcc fit them (kernel_resources.json: no scratch)
 template <typename T, int DP, int MODE>
-__global__ __launch_bounds__(256, (DP <= 64 ? 2 : 1)) void attention_bwd_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, ((DP <= 64 || (MODE == 0 && DP <= 96)) ? 2 : 1)) void attention_bwd_kernel(const AttnBwdParams p) {
     constexpr int EPC = 8;
     constexpr int DV = (DP + 31) / 32 * 32, NDB = DV / 32;
     constexpr int KP = DP + 8, VP = bwd_v_pitch(DV);     // row pitches (elements): row-read layout / transpose-read layout
