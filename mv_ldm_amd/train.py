@@ -1334,15 +1334,31 @@ class MVLDMTrainer:
                 t.record_stream(main)
             ev = torch.cuda.Event()
             ev.record(self._enc_stream)
-        self._prefetched = dict(ids=tuple(id(bt) for bt in batches), parts=parts, lats=lats, event=ev)
+        self._prefetched = dict(ids=self._batches_key(batches), parts=parts, lats=lats, event=ev)
+
+    @staticmethod
+    def _batches_key(batches):
+        """identity AND state of what was encoded ahead: the batch objects, their image tensors' storage and in-place version counters
+        (images, poses, ...: a loader that refills the same tensors in place must not get the previous contents' latents)"""
+        key = []
+        for bt in batches:
+            k = [id(bt)]
+            for side in ("context", "target"):
+                d_ = bt.get(side, {}) if isinstance(bt, dict) else {}
+                for name in sorted(d_):
+                    t = d_[name]
+                    if torch.is_tensor(t):
+                        k += [name, id(t), t.data_ptr(), t._version, tuple(t.shape)]
+            key.append(tuple(k))
+        return tuple(key)
 
     def _take_prefetched(self, batches):
         pre = self.__dict__.pop("_prefetched", None)
         if pre is None:
             return None
         torch.cuda.current_stream().wait_event(pre["event"])
-        if pre["ids"] != tuple(id(bt) for bt in batches):
-            return None               # prepared for other batches than the ones that came: encode these (the draw order is the caller's then)
+        if pre["ids"] != self._batches_key(batches):
+            return None               # prepared for other batches (or the same objects, modified since): encode what came (the draw order is the caller's then)
         return pre["parts"], pre["lats"]
 
     def training_window(self, batches: Sequence[dict], choices: Optional[Sequence[dict]] = None, prefetch=None) -> torch.Tensor:

@@ -618,3 +618,13 @@ def test_encoding_the_next_window_ahead_changes_nothing_but_the_time(golden):
     want = [float(x) for x in build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3)).training_window([b1, b1], ch)]
     tr._start_prefetch([b0, b0], None)
     assert [float(x) for x in tr.training_window([b1, b1], ch)] == want
+    # ... and the SAME batch objects refilled in place after they were encoded ahead (a loader reusing its buffers): encoded again
+    tr = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3))
+    import copy
+    bb = copy.deepcopy(b0)
+    tr._start_prefetch([bb, bb], None)
+    for side in ("context", "target"):
+        bb[side]["image"].copy_(b1[side]["image"])
+        for k_ in ("extrinsics", "intrinsics"):
+            bb[side][k_].copy_(b1[side][k_])
+    assert [float(x) for x in tr.training_window([bb, bb], ch)] == want
