@@ -46,13 +46,22 @@ from .plan import Builder, Plan
 # ================================================================================================ flat fp32 state
 class FlatParams:
     """fp32 master parameters and gradients of the TRAINED part of a module in two flat device buffers; every
-    `nn.Parameter` becomes a view (`p.data`, `p.grad`), so state dicts / checkpoints keep working.  Order = module
-    registration order (what `parameters()` yields), offsets aligned to 16 bytes."""
+    `nn.Parameter` becomes a view (`p.data`, `p.grad`), so state dicts / checkpoints keep working.  Order = the stacked `groups`
+    first, then module registration order (what `parameters()` yields); offsets aligned to 16 bytes."""
 
-    def __init__(self, module: nn.Module, exclude: Sequence[nn.Parameter] = ()):
+    def __init__(self, module: nn.Module, exclude: Sequence[nn.Parameter] = (), groups: Sequence[Sequence[nn.Parameter]] = ()):
+        """`groups`: parameter lists that one kernel treats as ONE stacked matrix (the 22 `time_emb_proj` weights / biases of the UNet's
+        resnets): laid out contiguously, in the given order, in front of everything else -- their stacked forward / gradient views are then
+        views of the flat buffers (no concatenated copy to refresh after every optimizer step, one weight-gradient launch for the stack)."""
         skip = {id(p) for p in exclude}
         self.module = module
-        self.params = [p for p in module.parameters() if id(p) not in skip and p.requires_grad]
+        front, seen = [], set()
+        for grp in groups:
+            for p in grp:
+                if id(p) not in skip and p.requires_grad and id(p) not in seen:
+                    front.append(p)
+                    seen.add(id(p))
+        self.params = front + [p for p in module.parameters() if id(p) not in skip and p.requires_grad and id(p) not in seen]
         self.excluded = [p for p in module.parameters() if id(p) in skip]
         assert self.params and all(p.dtype == torch.float32 for p in self.params), "FlatParams needs fp32 master parameters"
         self.offset: Dict[int, int] = {}
@@ -317,6 +326,10 @@ class TrainBuilder(Builder):
                 self.touched.add(id(p))
         if len(segments) == 1 and len(segments[0]) == 1:
             return segments[0][0].data
+        if all(len(sg) == 1 for sg in segments) and self.flat.contiguous([sg[0] for sg in segments]) \
+                and all(sg[0].numel() % 4 == 0 for sg in segments):
+            o = self.flat.offset[id(segments[0][0])]        # stacked in the flat buffer (FlatParams groups): a view, nothing to refresh
+            return self.flat.flat[o:o + sum(sg[0].numel() for sg in segments)]
         sizes = [sg[0].numel() for sg in segments]
         buf = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
         offs = np.cumsum([0] + sizes)
@@ -367,11 +380,15 @@ class TrainBuilder(Builder):
                 if biases or residual is not None:
                     par.lane()      # ---- bias sums, the residual branch's share of dY
                     off = 0
-                    for i, w in enumerate(weights):
-                        if biases:
-                            for p in biases[i]:
-                                self._colsum(dy[:, off:off + n_i[i]], n_i[i], self._pgrad(p), n_i[i], rows, False, not self._fw, "dbias")
-                        off += n_i[i]
+                    if biases and len(weights) > 1 and all(len(sg) == 1 for sg in biases) and self.flat.contiguous([sg[0] for sg in biases]):
+                        # the stacked biases are one flat range: one column-sum launch for all of them
+                        self._colsum(dy, sum(n_i), self._pgrad(biases[0][0], through=biases[-1][0]), sum(n_i), rows, False, not self._fw, "dbias")
+                    else:
+                        for i, w in enumerate(weights):
+                            if biases:
+                                for p in biases[i]:
+                                    self._colsum(dy[:, off:off + n_i[i]], n_i[i], self._pgrad(p), n_i[i], rows, False, not self._fw, "dbias")
+                            off += n_i[i]
                     if residual is not None:
                         self.add_grad(residual, dy)
         self.tape.append(backward)
@@ -1501,7 +1518,11 @@ def par_safe_cut(ops, end: int) -> int:
 
 
 def _flat_padded(denoiser, world: int) -> FlatParams:
-    flat = FlatParams(denoiser, exclude=never_trained(denoiser))
+    groups = ()
+    if hasattr(denoiser, "_resnets_in_order"):      # the stack `emit_unet_train` projects the time embedding with in ONE GEMM
+        rs = denoiser._resnets_in_order()
+        groups = ([r.time_emb_proj.weight for r in rs], [r.time_emb_proj.bias for r in rs])
+    flat = FlatParams(denoiser, exclude=never_trained(denoiser), groups=groups)
     q = world * 4
     if flat.numel % q:       # pad the buffers so that every bucket splits evenly over the ranks
         pad = q - flat.numel % q
