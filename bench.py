@@ -606,7 +606,7 @@ def main():
             small[f"b{sb}"] = {"views_per_s": round(sb * v_t / dt_s, 3), "sample_ms": round(dt_s * 1e3, 2),
                                "ddim_step_ms": round(step, 4), "two_roof": tr}
         out["small_batch"] = small
-        if b == 64 and not getattr(args, "no_large_batch", False):
+        if b == 64 and args.dtype != "f32" and not getattr(args, "no_large_batch", False):
             # ---- and the other side of 64 scenes: the 288 GB of one GPU take more, and the tile quantisation of the deep levels eases off
             # (`value` stays at 64 scenes per GPU, the configuration of every earlier round's line)
             lb_ = 128
