@@ -1263,6 +1263,7 @@ class MVLDMTrainer:
 
     def prepare(self, batch, **choices) -> TrainPlan:
         """stage ONE micro-batch into the plan of its shape (recorded on first use); returns the plan"""
+        self._take_prefetched(())           # a window encoded ahead (`_start_prefetch`) may still be using the encoder on its side stream: wait, drop it
         part = self._host_part(batch, **choices)
         part = self._finish_part(part, self._encode([part["x"]], [part["encode_noise"]])[0])
         lat = part["lat"]
@@ -1300,7 +1301,6 @@ class MVLDMTrainer:
         `accumulate_grad_batches`-th call also clips, steps AdamW and advances the LR schedule.  Returns the
         micro-batch's (unscaled) loss as a device scalar."""
         acc = self.cfg.accumulate_grad_batches
-        self._take_prefetched(())           # (a window encoded ahead for `training_window` is dropped: the encoder is about to be used here)
         if self.micro % acc == 0:
             if self.ema is not None:
                 self.ema.update()
@@ -1351,6 +1351,7 @@ class MVLDMTrainer:
                 t.record_stream(main)
             ev = torch.cuda.Event()
             ev.record(self._enc_stream)
+        self.autoencoder.__dict__["_busy_event"] = ev          # any other user of the encoder's plans (a validation sample on the main stream) waits for it
         self._prefetched = dict(ids=self._batches_key(batches), parts=parts, lats=lats, event=ev)
 
     @staticmethod

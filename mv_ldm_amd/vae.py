@@ -242,11 +242,20 @@ class AutoencoderKL(nn.Module):
             out.append(n % size)
         return out
 
+    def _wait_side_user(self):
+        """the recorded plans own ONE set of buffers: a caller that ran this module on a side stream (the trainer encoding the next
+        window ahead, `MVLDMTrainer._start_prefetch`) leaves its completion event here, and every later call -- on whatever stream --
+        waits for it first"""
+        ev = self.__dict__.get("_busy_event")
+        if ev is not None and torch.cuda.is_available():
+            torch.cuda.current_stream().wait_event(ev)
+
     def decode(self, z: torch.Tensor, dtype=None, pre_scale: float = 1.0, post_scale: float = 1.0, post_shift: float = 0.0,
                clamp01: bool = False):
         """diffusers `decode(z).sample`; the optional affine maps (`z * pre_scale`, `img * post_scale + post_shift`,
         clamp to [0,1]) ride in the boundary layout kernels (last_stage_decode, diffusion_wrapper.py:289-298)"""
         require_gpu(z)
+        self._wait_side_user()
         n, c, h, w = z.shape
         dtype = dtype or get_compute_dtype()
         outs, i0 = [], 0
@@ -263,6 +272,7 @@ class AutoencoderKL(nn.Module):
         """diffusers `encode(x).latent_dist`; `x * pre_scale + pre_shift` rides in the boundary layout kernel
         (first_stage_encode's `inputs * 2 - 1`, diffusion_wrapper.py:281)"""
         require_gpu(x)
+        self._wait_side_user()
         n, c, h, w = x.shape
         dtype = dtype or get_compute_dtype()
         outs, i0 = [], 0
