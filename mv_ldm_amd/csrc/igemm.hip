@@ -1278,10 +1278,14 @@ __device__ __forceinline__ void pack_fwd_k3_body(const mvldm_pack_job& j, int bx
         lds[r * 577 + e] = (n < j.n_out && c < j.c_in) ? src[((size_t)n * j.c_in + cb * 64) * 9 + e] : 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 4 * 576; i += 256) {
-        const int r = i / 576, o = i - r * 576;
+    // two consecutive output elements (channels cw, cw + 1 of one tap) per thread: 4-byte stores, 256 bytes per wave instruction
+    for (int i = threadIdx.x; i < 4 * 288; i += 256) {
+        const int r = i / 288, o = (i - r * 288) * 2;
         const int tap = o >> 6, cw = o & 63;
-        if (np0 + r < j.n_pad) dst[(size_t)(np0 + r) * j.k_pad + cb * 576 + o] = from_f32<T>(lds[r * 577 + cw * 9 + tap]);
+        if (np0 + r < j.n_pad) {
+            T pr[2] = {from_f32<T>(lds[r * 577 + cw * 9 + tap]), from_f32<T>(lds[r * 577 + (cw + 1) * 9 + tap])};
+            *reinterpret_cast<uint32_t*>(dst + (size_t)(np0 + r) * j.k_pad + cb * 576 + o) = *reinterpret_cast<const uint32_t*>(pr);
+        }
     }
 }
 // transposed (data-gradient) pack: rows = input channels, K = (64-output-channel block, flipped tap, output channel)
@@ -1298,10 +1302,15 @@ __device__ __forceinline__ void pack_t_body(const mvldm_pack_job& j, int bx, flo
         lds[nw * PITCH + e] = (n < j.n_out && r < j.n_rows) ? src[((size_t)n * j.c_in + j.c_off + r0) * TAPS + e] : 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * RUN; i += 256) {
-        const int nw = i & 63, q = i >> 6;
+    // two consecutive output channels per thread: 4-byte stores (the odd LDS pitch keeps the two reads on different banks)
+    for (int i = threadIdx.x; i < 32 * RUN; i += 256) {
+        const int nw = (i & 31) * 2, q = i >> 5;
         const int rl = q / TAPS, tp = q - rl * TAPS;
-        if (r0 + rl < j.n_pad) dst[(size_t)(r0 + rl) * j.k_pad + (nb * TAPS + tp) * 64 + nw] = from_f32<T>(lds[nw * PITCH + rl * TAPS + (TAPS - 1 - tp)]);
+        if (r0 + rl < j.n_pad) {
+            const int e = rl * TAPS + (TAPS - 1 - tp);
+            T pr[2] = {from_f32<T>(lds[nw * PITCH + e]), from_f32<T>(lds[(nw + 1) * PITCH + e])};
+            *reinterpret_cast<uint32_t*>(dst + (size_t)(r0 + rl) * j.k_pad + (nb * TAPS + tp) * 64 + nw) = *reinterpret_cast<const uint32_t*>(pr);
+        }
     }
 }
 
