@@ -1272,10 +1272,22 @@ __device__ __forceinline__ void pack_fwd_k3_body(const mvldm_pack_job& j, int bx
     const float* __restrict__ src = j.src;
     const int ncb = j.c_pad / 64;
     const int cb = bx % ncb, np0 = (bx / ncb) * 4;
-    for (int i = threadIdx.x; i < 4 * 576; i += 256) {
-        const int r = i / 576, e = i - r * 576;
-        const int n = np0 + r, c = cb * 64 + e / 9;
-        lds[r * 577 + e] = (n < j.n_out && c < j.c_in) ? src[((size_t)n * j.c_in + cb * 64) * 9 + e] : 0.f;
+    if (cb * 64 + 64 <= j.c_in && (j.c_in & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // whole 64-channel block inside the weight: 16-byte loads of the [c][tap] run (576 floats per output row, 16-byte aligned)
+        for (int i = threadIdx.x; i < 4 * 144; i += 256) {
+            const int r = i / 144, e = (i - r * 144) * 4;
+            const int n = np0 + r;
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (n < j.n_out) q = *reinterpret_cast<const f32x4*>(src + ((size_t)n * j.c_in + cb * 64) * 9 + e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds[r * 577 + e + u] = q[u];
+        }
+    } else {
+        for (int i = threadIdx.x; i < 4 * 576; i += 256) {
+            const int r = i / 576, e = i - r * 576;
+            const int n = np0 + r, c = cb * 64 + e / 9;
+            lds[r * 577 + e] = (n < j.n_out && c < j.c_in) ? src[((size_t)n * j.c_in + cb * 64) * 9 + e] : 0.f;
+        }
     }
     __syncthreads();
     // two consecutive output elements (channels cw, cw + 1 of one tap) per thread: 4-byte stores, 256 bytes per wave instruction
@@ -1296,10 +1308,22 @@ __device__ __forceinline__ void pack_t_body(const mvldm_pack_job& j, int bx, flo
     const float* __restrict__ src = j.src;
     const int nnb = j.c_pad / 64;
     const int nb = bx % nnb, r0 = (bx / nnb) * RB;
-    for (int i = threadIdx.x; i < 64 * RUN; i += 256) {
-        const int nw = i / RUN, e = i - nw * RUN;
-        const int n = nb * 64 + nw, r = r0 + e / TAPS;
-        lds[nw * PITCH + e] = (n < j.n_out && r < j.n_rows) ? src[((size_t)n * j.c_in + j.c_off + r0) * TAPS + e] : 0.f;
+    if (r0 + RB <= j.n_rows && (j.c_in & 3) == 0 && (j.c_off & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // the whole run of RB rows x TAPS lies inside the weight: 16-byte loads (RUN floats per output channel, 16-byte aligned)
+        for (int i = threadIdx.x; i < 64 * (RUN / 4); i += 256) {
+            const int nw = i / (RUN / 4), e = (i - nw * (RUN / 4)) * 4;
+            const int n = nb * 64 + nw;
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (n < j.n_out) q = *reinterpret_cast<const f32x4*>(src + ((size_t)n * j.c_in + j.c_off + r0) * TAPS + e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds[nw * PITCH + e + u] = q[u];
+        }
+    } else {
+        for (int i = threadIdx.x; i < 64 * RUN; i += 256) {
+            const int nw = i / RUN, e = i - nw * RUN;
+            const int n = nb * 64 + nw, r = r0 + e / TAPS;
+            lds[nw * PITCH + e] = (n < j.n_out && r < j.n_rows) ? src[((size_t)n * j.c_in + j.c_off + r0) * TAPS + e] : 0.f;
+        }
     }
     __syncthreads();
     // two consecutive output channels per thread: 4-byte stores (the odd LDS pitch keeps the two reads on different banks)
