@@ -166,7 +166,7 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
 
     # the frozen VAE encoder of the NEXT window runs on a side stream under this window's backward (same draws, same order, same
     # result; MVLDM_TRAIN_PREFETCH=0: encode at the start of the window's own call, A/B)
-    prefetch = window and os.environ.get("MVLDM_TRAIN_PREFETCH", "1") != "0"
+    prefetch = window and world == 1 and os.environ.get("MVLDM_TRAIN_PREFETCH", "1") != "0"      # (single-rank only: train.py training_window)
     win_b, win_c = [batch] * acc, [ch] * acc
 
     def opt_step():

@@ -1412,7 +1412,10 @@ class MVLDMTrainer:
             self._run_overlapped(tp)
         else:
             tp.run()
-        if prefetch is not None:        # the NEXT window's host part + VAE encode, on a side stream, under this window's backward
+        if prefetch is not None and not self.opt.collective:
+            # the NEXT window's host part + VAE encode, on a side stream, under this window's backward.  Single-rank runs only: beside
+            # the bucket collectives it is unverified on RCCL (no multi-GPU box here) and pathological on the test backend (two gloo
+            # ranks sharing one GPU: 2.6 -> 57 s per optimizer step) -- with collectives the window encodes at its own call
             self._start_prefetch(*prefetch)
         losses = tp.loss * acc
         self.micro += acc
