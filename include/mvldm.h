@@ -26,8 +26,9 @@ extern "C" {
 
 /* 3 (round 3): + mvldm_gather_rows, mvldm_ddpm_cfg_step, mvldm_ema_update; plan ops MVLDM_OP_PAR_BEGIN / _NEXT / _END and
  * MVLDM_OP_GATHER_ROWS / MVLDM_OP_ATTN_MERGE; bits 8-9 of mvldm_wgrad_desc.accumulate select the weight-gradient kernel form.  Everything of version 2 is
- * unchanged (additive). */
-#define MVLDM_ABI_VERSION 3
+ * unchanged (additive).
+ * 4 (round 5): + mvldm_pack_skinny and tile 15 / k_order 2 of mvldm_igemm_fwd (the skinny-M weight-streaming GEMM); additive over 3. */
+#define MVLDM_ABI_VERSION 4
 
 typedef void* mvldm_stream_t; /* hipStream_t */
 
@@ -84,9 +85,15 @@ typedef struct mvldm_igemm_desc {
                            12 = persistent Linear with the epilogue pipelined under the next tile (linear_pp.hip: 1x1, one or two
                            sources, K >= 320 a multiple of 64, 16-bit in and out; any other problem is an error, not a fallback),
                            13 = persistent wide Linear (linear_pw.hip), 14 = weight-stationary Linear for K = 320 (linear_ws.hip),
-                           18 = 192 x 128 tile with a 4-slot ring (igemm.hip; 1x1 / 3x3, no upsampling forms, no GEGLU: refused).
+                           18 = 192 x 128 tile with a 4-slot ring (igemm.hip; 1x1 / 3x3, no upsampling forms, no GEGLU: refused),
+                           15 = skinny-M weight-streaming GEMM (skinny.hip, round 5: launches of a few hundred rows -- one scene at the
+                                8x8 / 4x4 levels, mvunet.py:150-200 -- whose cost is the weight stream): `weight` is the FRAGMENT-ORDER
+                                pack of mvldm_pack_skinny (k_order must be 2), whole K per workgroup, no split-K slab and no reduce launch;
+                                1x1 / 3x3 (stride 1 or 2) / 2x2 phase convs, one or two sources, channels in multiples of 64, every
+                                epilogue; bits 8-13 = its configuration (0 = rule; a configuration that does not fit is an error).
                            Bits 0-5 = the tile id; bits 8-11 / 12 = tuning overrides (XCD grid, register-prefetch loop) */
-    int32_t k_order;    /* K order of the packed weight: 0 = (tap, channel); 1 = (64-channel block, tap, channel) */
+    int32_t k_order;    /* K order of the packed weight: 0 = (tap, channel); 1 = (64-channel block, tap, channel); 2 = the k_order-1
+                           sequence in MFMA-fragment order (mvldm_pack_skinny; tile 15 only) */
     int32_t dst_ld;     /* row stride of dst in elements; 0 = n_dst (dense).  > n_dst writes into a wider buffer */
     float out_scale;
     size_t workspace_bytes;
@@ -108,6 +115,14 @@ size_t mvldm_igemm_workspace_bytes(const mvldm_igemm_desc* d);
 int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksize, int c_pad, int n_pad,
                       int k_pad, int geglu, int k_order, int dst_dtype, int transpose, int c_off, int n_rows,
                       mvldm_stream_t stream);
+
+/* Re-order a K-major 16-bit pack made with k_order 1 (`packed`: [n_pad][k_pad], n_pad % 64 == 0, k_pad % 64 == 0) into the
+ * fragment order tile 15 of mvldm_igemm_fwd streams: 16-byte unit ((nt * (k_pad/32) + kg) * 64 + lane) of dst =
+ * packed[row(nt, lane & 15)][32 kg + 8 (lane >> 4) .. + 7], i.e. one v_mfma_f32_16x16x32 A-operand fragment (16 output columns x 32 k)
+ * is 1 KB of consecutive bytes and a 16-column tile is one contiguous stream over K.  row(nt, r) = 16 nt + r, except for a GEGLU
+ * pack (`geglu` != 0: rows alternate [32 value | 32 gate]) where tiles (2q, 2q+1) are the value / gate rows of output columns
+ * 16 q .. 16 q + 15.  Same byte count as `packed`.  replaces: nothing in the reference (a load-time transform like mvldm_pack_weight). */
+int mvldm_pack_skinny(const void* packed, void* dst, int n_pad, int k_pad, int geglu, int dtype, mvldm_stream_t stream);
 
 /* The same transform for MANY weights in one launch (round 3): after an optimizer step the training path re-packs every
  * trained weight (forward + data-gradient packs, ~380 of them) -- as one launch per pack these are latency-bound (7 ms for

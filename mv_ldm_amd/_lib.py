@@ -11,7 +11,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmvldm_hip.so"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_GEGLU, EPI_GELU = 0, 1, 2, 3
 RAYS_RAW, RAYS_POSITIONAL, RAYS_SRT = 0, 1, 2
@@ -187,6 +187,7 @@ SIGNATURES = {
     "mvldm_igemm_fwd": (C.c_int, [C.POINTER(IgemmDesc), vp]),
     "mvldm_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
     "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
+    "mvldm_pack_skinny": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mvldm_pack_job_prepare": (C.c_int, [C.POINTER(PackJob), C.c_int]),
     "mvldm_pack_weight_batch": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp, vp]),

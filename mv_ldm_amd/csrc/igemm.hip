@@ -1747,6 +1747,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
 int linear_pp_run(const mvldm_igemm_desc& d, hipStream_t s);
 int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s);
 int linear_ws_run(const mvldm_igemm_desc& d, hipStream_t s);      // tile 14: weight-stationary Linear for K = 320 (linear_ws.hip)
+int skinny_run(const mvldm_igemm_desc& d, hipStream_t s);         // tile 15: skinny-M weight-streaming GEMM on the fragment-order pack (skinny.hip)
 
 int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
     IgemmParams p;
@@ -1764,6 +1765,8 @@ int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
         MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
         return linear_ws_run(d, s);
     }
+    if ((d.tile & 63) == 15) return skinny_run(d, s);
+    MVLDM_REQUIRE(d.k_order != 2, "igemm: the fragment-order pack (k_order 2) is read by tile 15 only");
     int rc = fill_params(d, p, tile);
     if (rc) return rc;
     if (p.M == 0) return MVLDM_OK;

@@ -68,6 +68,25 @@ class PackedWeight:
     ksize: int
     geglu: bool = False
     k_order: int = 0    # 1: K stored as (channel block, tap, channel) -- needs every source's channels % BK == 0
+    _skinny: Optional[torch.Tensor] = None
+
+    def can_skinny(self) -> bool:
+        """does igemm tile 15 (csrc/skinny.hip) read this weight?  16-bit block-major packs whose channel count is a multiple of 64"""
+        return self.k_order == 1 and self.data.dtype != torch.float32 and self.c_pad % 64 == 0 and self.k_pad == self.ksize * self.ksize * self.c_pad \
+            and self.ksize in (1, 2, 3) and self.n_out % 4 == 0
+
+    def skinny(self) -> torch.Tensor:
+        """the same weight in MFMA-fragment order (`mvldm_pack_skinny`), made on first use from the K-major pack and kept with it: the
+        operand of igemm tile 15.  A re-pack produces a new PackedWeight (modules._PackMixin), so the copy cannot go stale."""
+        if self._skinny is None:
+            assert self.can_skinny(), "tile 15 needs a 16-bit block-major pack with channels in multiples of 64"
+            out = torch.empty_like(self.data)
+            L.check(L.load().mvldm_pack_skinny(self.data.data_ptr(), out.data_ptr(), self.n_pad, self.k_pad, int(self.geglu), dt(self.data), stream()))
+            self._skinny = out
+        return self._skinny
+
+    def drop_skinny(self):
+        self._skinny = None
 
 
 def block_k(dtype: torch.dtype) -> int:
@@ -173,6 +192,8 @@ def igemm_desc(src0, src1, pw: PackedWeight, dst, *, n_img, h_in, w_in, h_out, w
     d.dst_ld = 0
     d.k_order = pw.k_order
     assert not pw.k_order or c0 % block_k(src0.dtype) == 0, "weight packed block-major but the source split is unaligned"
+    if (tile & 63) == 15:       # the skinny weight-streaming kernel reads the fragment-order copy of the pack
+        d.weight, d.k_order = ptr(pw.skinny()), 2
     if ws is not None:
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     else:

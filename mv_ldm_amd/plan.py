@@ -57,6 +57,8 @@ class Builder:
         self._lane = 0                  # > 0 inside a parallel group (`parallel()`): which lane the next ops belong to
         self._lane_ws: dict = {}        # lane -> its own split-K / GroupNorm workspaces (lanes run concurrently)
         self._deferred: Optional[list] = None
+        self.skinny = True              # may launches of a few hundred rows take igemm tile 15 (the fragment-order pack of the weight)?
+        self._skinny_pw: dict = {}      # op index -> PackedWeight of the convs / Linears tile 15 could compute
 
     # ---- memory ---------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None) -> torch.Tensor:
@@ -201,15 +203,22 @@ class Builder:
         d.epilogue, d.act_dtype, d.dst_dtype = epilogue, dt(x), dt(out)
         if tile == 0 and _PIN_TILE() and x.dtype != torch.float32 and pw.k_order == 1:
             tile, splitk = _PIN_TILE(), 1        # (test knob MVLDM_IGEMM_TILE: one tile, one K pass for every 16-bit block-major launch, see _PIN_TILE)
+        m = n * ho * wo
+        can_sk = self.skinny and skinny_candidate(pw, m, c0, c1, upsample, x.dtype)
+        if tile == 0 and can_sk and _SKINNY_RULE and m <= _SKINNY_RULE_ROWS:
+            tile = 15                            # the rule: launches of a few hundred rows stream their weights (csrc/skinny.hip)
         d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
         d.dst_ld = out.shape[-1] if out.shape[-1] != n_dst else 0
         d.k_order = pw.k_order
+        if (tile & 63) == 15:
+            d.weight, d.k_order = ptr(pw.skinny()), 2
+        elif can_sk and self.record and tile == 0:
+            self._skinny_pw[len(self.ops)] = pw  # a plan-time candidate (autotune_igemm)
         assert not pw.k_order or c0 % (32 if x.dtype == torch.float32 else 64) == 0, f"{name}: block-major weight, unaligned source split"
         if ws is not None:
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
         else:
             d.workspace, d.workspace_bytes, d.splitk = None, 0, 1
-        m = n * ho * wo
         k_real = pw.ksize * pw.ksize * (c0 + c1)
         es = x.element_size()
         nbytes = (pw.n_out * k_real + n * h * w * (c0 + c1)) * es + m * n_dst * out.element_size() \
@@ -219,7 +228,7 @@ class Builder:
             own = self.__dict__.get("_own_ptrs", ())
             self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = tuple(t if (t is not None and t.data_ptr() in own) else None
                                                                               for t in (x, x2))
-        self._emit(op, name, 2.0 * m * pw.n_out * k_real, nbytes, (x, x2, pw.data, bias, row_bias, residual, out))
+        self._emit(op, name, 2.0 * m * pw.n_out * k_real, nbytes, (x, x2, pw.data, pw._skinny if (tile & 63) == 15 else None, bias, row_bias, residual, out))
         return out
 
     def small_launch(self, rows: int, n_out: int) -> bool:
@@ -248,7 +257,7 @@ class Builder:
             lanes.__exit__(None, None, None)
         return out
 
-    def _phase_conv(self, x, pw, bias, out, phase, name):
+    def _phase_conv(self, x, pw, bias, out, phase, name, tile=0, splitk=0):
         n, h, w, c0 = x.shape
         ws = self.splitk_ws()        # small batches: K = 4C is long and there are few output tiles -- let the library split K
         assert pw.ksize == 2 and pw.k_order == 1 and c0 == pw.c_pad
@@ -263,17 +272,24 @@ class Builder:
         d.n_out, d.n_pad, d.k_pad = pw.n_out, pw.n_pad, pw.k_pad
         d.row_bias_ld = 0
         d.epilogue, d.act_dtype, d.dst_dtype = L.EPI_NONE, dt(x), dt(out)
-        d.splitk, d.tile, d.out_scale = 0, 0, 1.0
+        m = n * h * w
+        can_sk = self.skinny and skinny_candidate(pw, m, c0, 0, False, x.dtype)
+        if tile == 0 and can_sk and _SKINNY_RULE and m <= _SKINNY_RULE_ROWS:
+            tile = 15
+        d.splitk, d.tile, d.out_scale = splitk, tile, 1.0
         d.dst_ld = 0
         d.k_order = 1
+        if (tile & 63) == 15:
+            d.weight, d.k_order = ptr(pw.skinny()), 2
+        elif can_sk and self.record and tile == 0:
+            self._skinny_pw[len(self.ops)] = pw
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-        m = n * h * w
         es = x.element_size()
         nbytes = (pw.n_out * 4 * c0 + (m * c0 if phase == 0 else 0)) * es + m * pw.n_out * es
         if self.record:
             own = self.__dict__.get("_own_ptrs", ())
             self.__dict__.setdefault("_tune_srcs", {})[len(self.ops)] = (x if x.data_ptr() in own else None, None)
-        self._emit(op, f"{name}.p{phase}", 2.0 * m * pw.n_out * 4 * c0, nbytes, (x, pw.data, bias, out))
+        self._emit(op, f"{name}.p{phase}", 2.0 * m * pw.n_out * 4 * c0, nbytes, (x, pw.data, pw._skinny if (tile & 63) == 15 else None, bias, out))
 
     def linear(self, x, pw: PackedWeight, bias=None, *, residual=None, epilogue=L.EPI_NONE, out_dtype=None, out=None,
                name="linear", row_bias=None):
@@ -455,7 +471,7 @@ class Builder:
         if autotune is None:
             autotune = os.environ.get("MVLDM_AUTOTUNE", "1") != "0"
         if autotune and torch.device(self.device).type == "cuda":
-            autotune_igemm(self.ops, srcs=self.__dict__.get("_tune_srcs"))
+            autotune_igemm(self.ops, srcs=self.__dict__.get("_tune_srcs"), skinny=self._skinny_pw, keep=self.keep)
             autotune_wgrad(self.ops)
         return Plan(self.ops, self.meta, self.keep, self.device)
 
@@ -540,12 +556,29 @@ _MID_SPLITS = (0, 1, 2, 3, 4, 6, 8)
 _SMALL_TILES = tuple(int(t) for t in os.environ.get("MVLDM_TUNE_SMALL_TILES", "0,1,2,3,4,5").split(","))
 
 
+# ---- igemm tile 15 (csrc/skinny.hip): the skinny-M weight-streaming kernel.  It reads the FRAGMENT-ORDER copy of the packed weight
+# (`PackedWeight.skinny()`, made on first use), so a choice of tile 15 swaps the descriptor's weight pointer and sets k_order = 2.
+# Candidates: 16-bit block-major convs / Linears of at most MVLDM_SKINNY_ROWS output rows whose channel counts are multiples of 64.
+# MVLDM_SKINNY=0 keeps it out of the plans (A/B knob); MVLDM_SKINNY_RULE=1 makes it the RULE for launches of at most
+# MVLDM_SKINNY_RULE_ROWS rows (used when plan-time tuning is off; with tuning on it is one more candidate, timed like the tiles).
+_SKINNY = os.environ.get("MVLDM_SKINNY", "1") != "0"
+_SKINNY_ROWS = int(os.environ.get("MVLDM_SKINNY_ROWS", "2304"))
+_SKINNY_RULE = os.environ.get("MVLDM_SKINNY_RULE", "0") == "1"
+_SKINNY_RULE_ROWS = int(os.environ.get("MVLDM_SKINNY_RULE_ROWS", "576"))
+_SKINNY_CFGS = tuple(int(c) for c in os.environ.get("MVLDM_SKINNY_CFGS", "0,1,2,5,6,7,8,9,10,12,13,18,19,20,32,33,34,36,37,38,39,40,41,42,43,44,45,46").split(","))
+
+
+def skinny_candidate(pw: PackedWeight, rows: int, c0: int, c1: int, upsample, dtype) -> bool:
+    return (_SKINNY and dtype != torch.float32 and rows <= _SKINNY_ROWS and not (upsample is True or upsample == 1) and pw.can_skinny()
+            and c0 % 64 == 0 and c1 % 64 == 0)
+
+
 def _unpack_choice(v):
     """a cache entry is the tile (int: files of earlier rounds) or [tile, splitk]; splitk None = leave the descriptor's"""
     return (int(v), None) if isinstance(v, int) else (int(v[0]), None if v[1] is None else int(v[1]))
 
 
-def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
+def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=None, keep=None) -> int:
     """set `desc.tile` of every auto-tiled 16-bit block-major igemm op with >= `min_rows` output rows to the
     fastest candidate; returns the number of distinct problems timed.  `srcs`: {op index: (x, x2)} source tensors of
     the recorded convs -- they hold scratch at this point and are filled with N(0,1) first: on zeros / NaNs the
@@ -567,17 +600,18 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
                         gen = torch.Generator(device=t.device)
                         gen.manual_seed(0x5EED)
                     t.normal_(generator=gen)
-    for op in ops:
+    for idx, op in enumerate(ops):
         if op.kind != L.OP_IGEMM:
             continue
         d = op.u.igemm
         rows = d.n_img * d.h_out * d.w_out
-        if d.tile != 0 or d.act_dtype == L.F32 or d.k_order != 1 or rows < min(min_rows, _SMALL_ROWS):
+        sk_pw = (skinny or {}).get(idx)      # tile 15 can compute this op: even launches below MVLDM_TUNE_SMALL_ROWS are worth timing then
+        if d.tile != 0 or d.act_dtype == L.F32 or d.k_order != 1 or (rows < min(min_rows, _SMALL_ROWS) and sk_pw is None):
             continue
         small = rows < min_rows
-        key = _igemm_signature(d)
+        key = _igemm_signature(d) + (("sk",) if sk_pw is not None else ())
         best = _TUNE_CACHE.get(key)
-        if best is not None and _unpack_choice(best)[0] not in (set(_TUNE_TILES) | set(_SMALL_TILES)):
+        if best is not None and (_unpack_choice(best)[0] & 63) not in (set(_TUNE_TILES) | set(_SMALL_TILES) | ({15} if sk_pw is not None else set())):
             best = None          # an entry of an older build / another candidate set (a tile this build no longer offers): time it again
         if best is None:
             trial = L.Op()
@@ -589,10 +623,14 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
             cands = [(t, sk) for t in _TUNE_TILES for sk in _MID_SPLITS] if mid else [(t, None) for t in _TUNE_TILES] if not small else \
                     [(t, sk) for t in _SMALL_TILES if t in _TUNE_TILES or not os.environ.get("MVLDM_TUNE_TILES") for sk in (_SPLITS if can_split else (None,))]
             n_it = iters if not small else 3 * iters
+            if sk_pw is not None:            # tile 15 in every configuration the library accepts for this problem (others return an error)
+                cands = cands + [(15 | (c << 8), 1) for c in _SKINNY_CFGS]
+                sk_ptr = sk_pw.skinny().data_ptr()
             results = []
             for tile, sk in cands:
                 trial.u.igemm.tile = tile
                 trial.u.igemm.splitk = d.splitk if sk is None else sk
+                trial.u.igemm.weight, trial.u.igemm.k_order = (sk_ptr, 2) if (tile & 63) == 15 else (d.weight, d.k_order)
                 if lib.mvldm_op_run(C.byref(trial), stream) != 0:      # candidate not applicable to this problem
                     continue
                 e0.record()
@@ -611,6 +649,13 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None) -> int:
         d.tile = tile
         if sk is not None:
             d.splitk = sk
+        if (tile & 63) == 15:                # the fragment-order copy of the weight stays with the plan
+            t = sk_pw.skinny()
+            d.weight, d.k_order = t.data_ptr(), 2
+            if keep is not None:
+                keep.append(t)
+        elif sk_pw is not None:
+            sk_pw.drop_skinny()              # not chosen: the copy made for the trials is not kept
     if timed:
         save_tune_cache()
     return timed

@@ -128,6 +128,7 @@ class TrainBuilder(Builder):
     def __init__(self, device, dtype, flat: FlatParams, ws_bytes: int = 512 << 20, store_first: bool = False):
         assert dtype in (torch.float32, torch.bfloat16), "training runs in bf16 (fp32 accumulation / master weights) or f32"
         super().__init__(device, dtype, record=True)
+        self.skinny = False             # the training packs are refreshed in place after every optimizer step: no fragment-order copies
         self.flat = flat
         # plans that run ONCE per accumulation window (training_window): the first write of every gradient range is a store (grad = ...),
         # later ones accumulate; the caller then needs no zeroed gradient buffer (FlatParams.begin_window)

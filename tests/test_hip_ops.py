@@ -185,6 +185,162 @@ def test_geglu(ops, dtype, rows, c):
             close(y.float().cpu().double(), ref, dtype, f"geglu tile{tile}")
 
 
+# ---- tile 15: the skinny-M weight-streaming GEMM (csrc/skinny.hip).  Configurations ride in bits 8-11 of `tile`:
+#   3x3: 1 = 48 rows, 2 = 64 rows, 3 = 144 rows, 18 = 192 rows, 14 / 15 = 48 / 64 rows x 32 columns, 16 / 17 = 48 / 64 rows with two channel blocks
+#   per stage, 21 / 22 / 23 = balanced 8-wave form (48 / 64 / 48 rows); stride 2: 4 = 16 rows, 5 = 48 rows, 24 = 16 rows balanced; 2x2 phase: 6 = 48 rows, 7 = 64 rows, 19 = 192 rows;
+#   1x1 / Linear: 8 = 48 x 64, 9 = 48 x 32, 10 = 16 x 64, 20 = 16 x 32, 11 = 144 x 16, 12 = 48 x 16, 13 = 96 x 32;
+#   32 ... 46: the independent-wave-streams form (no barrier in the loop): 3x3 32 / 33 / 45 (48 / 64 / 96 rows), stride 2 34, phases 36 / 37, Linear 38 ... 44, 46
+def sk(cfg=0):
+    return 15 | (cfg << 8)
+
+
+SKINNY_CONV = [
+    # name, n, cin, cin2, cout, h, w, k, stride, pad, configurations
+    ("3x3_4x4_nine", 9, 128, 0, 192, 4, 4, 3, 1, 1, (0, 1, 3, 14, 16, 18, 21, 23, 32, 45)),
+    ("3x3_4x4_ragged_images", 7, 192, 0, 320, 4, 4, 3, 1, 1, (1, 3, 14, 16, 21, 32, 45)),        # 7 images: groups of 3 / 9 are ragged
+    ("3x3_8x8", 5, 128, 0, 128, 8, 8, 3, 1, 1, (0, 2, 15, 17, 18, 22, 33)),
+    ("3x3_2x2", 9, 64, 0, 64, 2, 2, 3, 1, 1, (0, 1, 3, 32)),                         # configs[0]'s deepest levels (8x8 latents)
+    ("3x3_1x1", 9, 64, 0, 64, 1, 1, 3, 1, 1, (0, 1)),
+    ("3x3_stride2", 9, 128, 0, 128, 8, 8, 3, 2, 1, (0, 4, 5, 24, 34)),
+    ("3x3_stride2_asym_vae", 3, 64, 0, 64, 8, 8, 3, 2, 0, (4, 5, 34)),
+    ("1x1_shortcut_concat", 9, 128, 192, 320, 4, 4, 1, 1, 0, (0, 8, 9, 10, 12, 13, 20, 38, 39, 40, 44)),
+    ("1x1_8x8", 9, 320, 0, 100, 8, 8, 1, 1, 0, (0, 8, 10, 13, 38, 42, 43)),                  # n_out 100 -> n_pad 128: columns past n_out are masked
+    ("3x3_wide_K", 9, 2560, 0, 64, 4, 4, 3, 1, 1, (1, 21, 23, 32)),                         # 40 channel blocks: 4 rounds of the ring
+    ("3x3_short_K", 9, 192, 0, 64, 4, 4, 3, 1, 1, (1, 14, 16, 21, 32)),                      # 3 channel blocks: less than one round (stages past K read zeros)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", SKINNY_CONV, ids=[c[0] for c in SKINNY_CONV])
+def test_skinny_tile_convs(ops, case, dtype):
+    """tile 15 against fp64 torch on every geometry it takes: 3x3 (stride 1 / 2, VAE's asymmetric pad), 1x1, one and two sources, images of
+    1 ... 64 pixels, ragged image groups, K shorter and longer than the weight ring, every configuration that fits"""
+    name, n, cin, cin2, cout, h, w, k, stride, pad, cfgs = case
+    ws = 1.0 / math.sqrt((cin + cin2) * k * k)
+    x = rnd((n, cin, h, w), 101, dtype)
+    x2 = rnd((n, cin2, h, w), 102, dtype) if cin2 else None
+    wt = rnd((cout, cin + cin2, k, k), 103, dtype, ws)
+    b = torch.randn(cout, generator=G(104)) * 0.1
+    xr = (x if x2 is None else torch.cat([x, x2], 1)).double()
+    if k == 3 and stride == 2 and pad == 0:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    ref = F.conv2d(xr, wt.double(), b.double(), stride=stride, padding=pad)
+    pw = ops.pack_weight(wt.cuda(), dtype, c_split=cin if cin2 else None)
+    for cfg in cfgs:
+        y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=None if x2 is None else nhwc(x2, dtype), stride=stride, pad=pad, tile=sk(cfg))
+        close(nchw(y), ref, dtype, f"{name} cfg{cfg}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_skinny_tile_epilogues(ops, dtype):
+    """+bias +per-image time-embedding row +residual (also in place), SiLU / GELU, fp32 output, out_scale, a wider destination"""
+    n, cin, cout, h = 9, 128, 192, 4
+    x, wt = rnd((n, cin, h, h), 111, dtype), rnd((cout, cin, 3, 3), 112, dtype, 1 / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=G(113)) * 0.1
+    rb = torch.randn(n, cout, generator=G(114))
+    res = rnd((n, cout, h, h), 115, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    base = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    for cfg in (1, 3, 14, 21, 32):
+        y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), row_bias=rb.cuda(), residual=nhwc(res, dtype), tile=sk(cfg))
+        close(nchw(y), base + rb.double()[:, :, None, None] + res.double(), dtype, f"temb+residual cfg{cfg}")
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), epilogue=1, out_dtype=torch.float32, out_scale=0.5, tile=sk(1))
+    assert y.dtype == torch.float32
+    close(nchw(y), F.silu(base) * 0.5, dtype, "silu/f32/scale")
+    y = ops.conv2d(nhwc(x, dtype), pw, None, epilogue=3, tile=sk(1))
+    close(nchw(y), F.gelu(base - b.double()[None, :, None, None]), dtype, "gelu, no bias")
+    r = nhwc(res, dtype)
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), residual=r, out=r, tile=sk(1))       # x += f(x)
+    assert y.data_ptr() == r.data_ptr()
+    close(nchw(y), base + res.double(), dtype, "in-place residual")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,cin,cout", [(144, 1280, 1280), (576, 640, 320), (9, 320, 1280), (100, 5120, 1280), (37, 64, 64)],
+                         ids=["144x1280", "576x640", "temb_9", "ffout_5120", "ragged_37"])
+def test_skinny_tile_linear(ops, dtype, rows, cin, cout):
+    x, wt = rnd((rows, cin), 121, dtype), rnd((cout, cin), 122, dtype, 1 / math.sqrt(cin))
+    b = torch.randn(cout, generator=G(123)) * 0.1
+    res = rnd((rows, cout), 124, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    ref = F.linear(x.double(), wt.double(), b.double()) + res.double()
+    for cfg in (0, 8, 9, 10, 11, 12, 13, 20, 38, 39, 40, 41, 42, 43, 44, 46):
+        y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), residual=res.to(dtype).cuda(), tile=sk(cfg))
+        close(y.float().cpu().double(), ref, dtype, f"linear cfg{cfg}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,c", [(144, 1280), (50, 64), (576, 320)])
+def test_skinny_tile_geglu(ops, dtype, rows, c):
+    """GEGLU: the fragment-order pack pairs value / gate tiles; odd column-tile counts per workgroup are refused"""
+    import mv_ldm_amd._lib as L
+    x, wt = rnd((rows, c), 131, dtype), rnd((8 * c, c), 132, dtype, 1 / math.sqrt(c))
+    b = torch.randn(8 * c, generator=G(133)) * 0.1
+    pw = ops.pack_weight(wt.cuda(), dtype, geglu=True)
+    a, g = F.linear(x.double(), wt.double(), b.double()).chunk(2, -1)
+    ref = a * F.gelu(g)
+    for cfg in (0, 8, 9, 10, 13, 20, 39, 40, 41, 42, 44, 46):
+        y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=sk(cfg))
+        assert y.shape == (rows, 4 * c)
+        close(y.float().cpu().double(), ref, dtype, f"geglu cfg{cfg}")
+    with pytest.raises(L.MvldmError):
+        ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=sk(12))        # one column tile per workgroup cannot pair value and gate
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,c,cout,h,w", [(9, 128, 128, 4, 4), (9, 64, 320, 8, 8), (5, 128, 64, 2, 2)], ids=["4x4", "8x8", "2x2"])
+def test_skinny_tile_upsample_phases(ops, dtype, n, c, cout, h, w):
+    """the four 2x2 phase convs of nearest-2x + 3x3 through tile 15 (rows scattered to (2i+py, 2j+px))"""
+    x = rnd((n, c, h, w), 141, dtype)
+    wt = rnd((cout, c, 3, 3), 142, dtype, 1 / math.sqrt(c * 9))
+    b = torch.randn(cout, generator=G(143)) * 0.1
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), wt.double(), b.double(), padding=1)
+    pws = [ops.pack_weight(t.cuda(), dtype) for t in ops.upsample_phase_weights(wt)]
+    for cfg in (0, 6, 19, 36) if h * w <= 16 else (0, 7, 19, 37):
+        y = ops.conv2d_upsample_phases(nhwc(x, dtype), pws, b.cuda(), tile=sk(cfg))
+        close(nchw(y), ref, dtype, f"phases cfg{cfg}")
+
+
+def test_skinny_tile_is_deterministic_and_refuses_what_it_cannot_do(ops):
+    """bit-identical launch after launch under memory-system noise (counted waits over LDS-DMA pieces and register loads in one in-order
+    queue; the waves' partial tiles are folded in wave order); f32, channels that are not multiples of 64, a K-major pointer, a configuration
+    that does not fit the problem are errors, never fallbacks"""
+    import mv_ldm_amd._lib as L
+    torch.manual_seed(0)
+    side, noise = torch.cuda.Stream(), torch.randn(16 << 20, device="cuda")
+    for n, hh, cin, cout, k in ((9, 4, 1280, 1280, 3), (9, 8, 1280, 640, 1), (36, 4, 640, 1280, 3)):
+        x = torch.randn(n, hh, hh, cin, device="cuda").to(torch.bfloat16)
+        pw = ops.pack_weight(torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5, torch.bfloat16)
+        b = torch.randn(cout, device="cuda")
+        ref = ops.conv2d(x, pw, b, tile=15).clone()
+        ref2 = ops.conv2d(x, pw, b, tile=2)
+        assert (ref.float() - ref2.float()).abs().max().item() <= 2e-2 * ref2.float().abs().max().item()
+        for i in range(40):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    noise.mul_(1.0001)
+            assert torch.equal(ops.conv2d(x, pw, b, tile=15), ref), (n, hh, i)
+    torch.cuda.synchronize()
+    x = torch.randn(9, 4, 4, 128, device="cuda")
+    with pytest.raises((L.MvldmError, AssertionError)):
+        ops.conv2d(x, ops.pack_weight(torch.randn(64, 128, 3, 3, device="cuda"), torch.float32), tile=15)           # f32
+    with pytest.raises((L.MvldmError, AssertionError)):
+        ops.conv2d(x[..., :96].contiguous().bfloat16(), ops.pack_weight(torch.randn(64, 96, 3, 3, device="cuda"), torch.bfloat16), tile=15)   # 96 channels
+    pw = ops.pack_weight(torch.randn(64, 128, 3, 3, device="cuda"), torch.bfloat16)
+    with pytest.raises(L.MvldmError):
+        ops.conv2d(x.bfloat16(), ops.pack_weight(torch.randn(64, 192, 3, 3, device="cuda"), torch.bfloat16, c_split=128), x2=x[..., :64].contiguous().bfloat16(), tile=15)   # two sources: 1x1 only
+    with pytest.raises(L.MvldmError):
+        ops.conv2d(x.bfloat16(), pw, tile=sk(8))                 # a Linear configuration on a 3x3 conv
+    with pytest.raises(L.MvldmError):
+        ops.conv2d(torch.randn(2, 8, 8, 128, device="cuda").bfloat16(), pw, tile=sk(1))      # 64-pixel images do not fit 48 rows
+    d = ops.igemm_desc(x.bfloat16(), None, pw, torch.empty(9, 4, 4, 64, device="cuda", dtype=torch.bfloat16), n_img=9, h_in=4, w_in=4, h_out=4, w_out=4)
+    d.tile = 15                                                   # K-major pointer with k_order 1: refused
+    import ctypes as C
+    assert L.load().mvldm_igemm_fwd(C.byref(d), 0) != 0
+    d.tile, d.k_order = 2, 2                                      # and the fragment-order pack is refused by every other tile
+    assert L.load().mvldm_igemm_fwd(C.byref(d), 0) != 0
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_deep_ring_tile_for_small_launches(ops, dtype):
     """tile 18 (192 x 128, 8 waves of 96 x 32, 4-slot ring: the weight-bound launches of a few scenes -- up to 192 rows fetch every
