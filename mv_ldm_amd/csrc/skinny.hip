@@ -67,12 +67,12 @@ template <> struct SkMma<f16_t> {
 
 constexpr int sk_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }   // s_waitcnt vmcnt(n) only (gfx9 encoding)
 
-// compile-time geometry of one instantiation.  BAL: the balanced 3x3 form -- 8 waves, 4 channel blocks per stage; wave w owns tap w of
-// all 8 (channel block, k-step) pairs of a stage plus tap 8 of pair w: 9 items per wave (with one tap per wave, nine waves sit 3/2/2/2 on
-// the four SIMDs and a stage is only 2 items: the per-stage issue overhead -- barrier, refill addressing -- then costs more than its MFMAs)
-template <int TAPS_, int NW_, int SC_, int MT_, int NT_, int DS_, int SM_, bool BAL_ = false, bool DUAL_ = false> struct SkCfg {
+// compile-time geometry of one instantiation.  (A "balanced" 3x3 form -- 8 waves, 4 channel blocks per stage, wave w owns tap w of all 8
+// (channel block, k-step) pairs plus tap 8 of pair w: 27 MFMAs per barrier instead of 6 -- was built and measured EQUAL to the
+// tap-per-wave form, 14.8 against 14.7 us on the 4x4-level conv: the cost per stage is its lockstep phases, see the loop; removed.)
+template <int TAPS_, int NW_, int SC_, int MT_, int NT_, int DS_, int SM_, bool DUAL_ = false> struct SkCfg {
     static constexpr int TAPS = TAPS_, NW = NW_, SC = SC_, MT = MT_, NT = NT_, DS = DS_, SM = SM_;
-    static constexpr bool BAL = BAL_, DUAL = DUAL_;           // DUAL: two sources concatenated along the channels (1x1 shortcut convs)
+    static constexpr bool DUAL = DUAL_;                      // two sources concatenated along the channels (1x1 shortcut convs)
     static constexpr int SRP = MT * 16 * SM;                 // source pixel rows of the workgroup's images (SM = 4: stride-2 conv)
     static constexpr int CBS = (SRP + 8) * 128;              // one 64-channel block of a slot: the rows + 8 rows of zeros
     static constexpr int SLOT = SC * CBS;
@@ -81,14 +81,13 @@ template <int TAPS_, int NW_, int SC_, int MT_, int NT_, int DS_, int SM_, bool 
     static constexpr int PIECES = SC * PPC;                  // ... per stage
     static constexpr int PA = (PIECES + NW - 1) / NW;        // ... per wave
     static constexpr int ITEMS = SC * TAPS * 2 / NW;         // (channel block, tap, k-step) items per wave and stage
-    static constexpr int ASETS = BAL ? 2 : 1;                // per-lane fragment address sets (taps) a wave reads with
     static constexpr int PARK = NW * MT * NT * 1024;
     static constexpr int DUMP = (RING > PARK ? RING : PARK); // 1 KB: where the surplus DMA pieces of the last wave land
     static constexpr int SMEM = DUMP + 1024;
     static constexpr int WAIT = (DS - 2) * (PA + ITEMS * NT) + ITEMS * NT;   // what may be in flight when A(s) must have landed (see the loop)
     static constexpr int WAIT_B = (DS - 2) * (PA + ITEMS * NT);               // ... for the waves that issue before they compute
     static constexpr bool STAGGER = NW >= 8;                                  // two wave groups with swapped phases (the loop's comment)
-    static_assert((SC * TAPS * 2) % NW == 0 && (BAL ? (TAPS == 9 && NW == 8 && SC == 4) : NW % TAPS == 0), "items must divide over the waves");
+    static_assert((SC * TAPS * 2) % NW == 0 && NW % TAPS == 0, "items must divide over the waves with one tap per wave");
     static_assert(DS >= 3 && WAIT <= 63, "ring depth / wait count");
     static_assert(SMEM <= 160 * 1024, "LDS");
 };
@@ -96,13 +95,8 @@ template <int TAPS_, int NW_, int SC_, int MT_, int NT_, int DS_, int SM_, bool 
 // item ii of wave `wave` in a stage -> (tap, channel block inside the stage, k-step)
 struct SkItem { int tap, cbl, ks; };
 template <typename C> __device__ __forceinline__ SkItem sk_item(int wave, int ii) {
-    if constexpr (C::BAL) {
-        if (ii < 8) return {wave, ii >> 1, ii & 1};
-        return {8, wave >> 1, wave & 1};
-    } else {
-        const int it = wave + C::NW * ii, kk = it / C::TAPS;
-        return {it % C::TAPS, kk >> 1, kk & 1};
-    }
+    const int it = wave + C::NW * ii, kk = it / C::TAPS;
+    return {it % C::TAPS, kk >> 1, kk & 1};
 }
 
 // ---- the epilogue both kernels share: the waves' partial tiles are folded through LDS in wave order (deterministic), then bias /
@@ -299,12 +293,11 @@ __global__ __launch_bounds__(C::NW * 64) void skinny_kernel(const SkParams p) {
         *reinterpret_cast<u32x4*>(smem + (blk / C::SC) * C::SLOT + (blk % C::SC) * C::CBS + C::SRP * 128 + (z & 63) * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 
-    // ---- per-lane fragment addresses: row tile i, tap -> LDS byte offset of (shifted source pixel, 16-byte chunk lane >> 4) of k-step 0
-    // inside a channel block; k-step 1 = the same ^ 64 (the swizzle is an XOR of the chunk index).  Set 0: this wave's tap; BAL: set 1 = tap 8
-    int aoff[C::ASETS][MT];
-#pragma unroll
-    for (int a = 0; a < C::ASETS; ++a) {
-        const int tap = a ? 8 : (C::BAL ? wave : wave % C::TAPS);
+    // ---- per-lane fragment addresses: row tile i of this wave's tap -> LDS byte offset of (shifted source pixel, 16-byte chunk lane >> 4) of
+    // k-step 0 inside a channel block; k-step 1 = the same ^ 64 (the swizzle is an XOR of the chunk index); padding taps -> the rows of zeros
+    int aoff[MT];
+    {
+        const int tap = wave % C::TAPS;
         const int ty = tap / p.ksize, tx = tap - ty * p.ksize;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -314,7 +307,7 @@ __global__ __launch_bounds__(C::NW * 64) void skinny_kernel(const SkParams p) {
             const int iy = oy * p.stride + p.ty0 + ty, ix = ox * p.stride + p.tx0 + tx;
             const bool ok = r < rows && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
             const int srow = ok ? il * p.hw_in + iy * p.w_in + ix : C::SRP;
-            aoff[a][i] = srow * 128 + ((((lane >> 4) ^ (srow >> 1)) & 7) << 4);
+            aoff[i] = srow * 128 + ((((lane >> 4) ^ (srow >> 1)) & 7) << 4);
         }
     }
     constexpr int NFO = MT <= 6 ? ITEMS : 1;   // (many row tiles: the offsets are formed at the read, one v_xor each, instead of kept)
@@ -324,12 +317,11 @@ __global__ __launch_bounds__(C::NW * 64) void skinny_kernel(const SkParams p) {
 #pragma unroll
     for (int ii = 0; ii < ITEMS; ++ii) {
         const SkItem it = sk_item<C>(wave, ii);
-        const int as = (C::BAL && ii == 8) ? 1 : 0;
         it_off[ii] = it.cbl * C::CBS;
         it_x[ii] = it.ks * 64;
         if (ii < NFO) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) foff[ii][i] = it.cbl * C::CBS + (aoff[as][i] ^ (it.ks * 64));
+            for (int i = 0; i < MT; ++i) foff[ii][i] = it.cbl * C::CBS + (aoff[i] ^ (it.ks * 64));
         }
         st.w_voff[ii] = (unsigned)lane * 16u + (unsigned)((it.cbl * C::TAPS + it.tap) * 2 + it.ks) * 1024u;
     }
@@ -409,7 +401,7 @@ __global__ __launch_bounds__(C::NW * 64) void skinny_kernel(const SkParams p) {
     }
     auto frag_off = [&](int ii, int i) -> int {
         if constexpr (MT <= 6) return foff[ii][i];
-        else return it_off[ii] + (aoff[0][i] ^ it_x[ii]);
+        else return it_off[ii] + (aoff[i] ^ it_x[ii]);
     };
     const int n_rounds = (p.n_stages + DS - 1) / DS;
     const bool grp_b = C::STAGGER && wave >= 4 && wave < 8;
@@ -561,18 +553,25 @@ __global__ __launch_bounds__(C::NW * 64) void skinny_iws_kernel(const SkParams p
     // per-lane fragment addresses: (tap, row tile) -> LDS byte offset of (shifted source pixel, 16-byte chunk lane >> 4) of k-step 0
     // inside a slot; k-step 1 = the same ^ 64 (the swizzle is an XOR of the chunk index); padding taps point at the rows of zeros
     int aoff[TAPS][MT];
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const int ty = tap / p.ksize, tx = tap - ty * p.ksize;
+    {
+        int p_il[MT], p_oy[MT], p_ox[MT];             // (image, y, x) of the lane's output pixel in each row tile: once, not per tap
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int r = i * 16 + (lane & 15);
             const int il = p.hw_sh >= 0 ? r >> p.hw_sh : r / p.hw_out, rem = r - il * p.hw_out;
-            const int oy = p.w_sh >= 0 ? rem >> p.w_sh : rem / p.w_out, ox = rem - oy * p.w_out;
-            const int iy = oy * p.stride + p.ty0 + ty, ix = ox * p.stride + p.tx0 + tx;
-            const bool ok = r < rows && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
-            const int srow = ok ? il * p.hw_in + iy * p.w_in + ix : C::SRP;
-            aoff[tap][i] = srow * 128 + ((((lane >> 4) ^ (srow >> 1)) & 7) << 4);
+            const int oy = p.w_sh >= 0 ? rem >> p.w_sh : rem / p.w_out;
+            p_il[i] = r < rows ? il : -1; p_oy[i] = oy * p.stride + p.ty0; p_ox[i] = (rem - oy * p.w_out) * p.stride + p.tx0;
+        }
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ty = tap / p.ksize, tx = tap - ty * p.ksize;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int iy = p_oy[i] + ty, ix = p_ox[i] + tx;
+                const bool ok = p_il[i] >= 0 && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
+                const int srow = ok ? p_il[i] * p.hw_in + iy * p.w_in + ix : C::SRP;
+                aoff[tap][i] = srow * 128 + ((((lane >> 4) ^ (srow >> 1)) & 7) << 4);
+            }
         }
     }
     // per-lane source offsets of the LDS-DMA pieces (row, swizzled chunk; the channel block rides in the scalar offset)
@@ -678,48 +677,39 @@ __global__ __launch_bounds__(256) void pack_skinny_kernel(const u32x4* __restric
 struct SkinnyCfgInfo { int taps, nw, sc, mt, nt, ds, sm, bal; };     // (sc = 0: the independent-wave-streams form)
 static const SkinnyCfgInfo kSkCfgs[] = {
     {0, 0, 0, 0, 0, 0, 0, 0},
-    {9, 9, 1, 3, 1, 10, 1, 0},    // 1: 3x3, 48 rows (three 4x4 images / ...)
-    {9, 9, 1, 4, 1, 10, 1, 0},    // 2: 3x3, 64 rows (one 8x8 image)
-    {9, 9, 1, 9, 1, 5, 1, 0},     // 3: 3x3, 144 rows (nine 4x4 images: every weight byte read by one workgroup)
-    {9, 9, 1, 1, 1, 10, 4, 0},    // 4: 3x3 stride 2, 16 output rows from 64 source rows (one 8x8 -> 4x4 image)
-    {9, 9, 1, 3, 1, 5, 4, 0},     // 5: 3x3 stride 2, 48 output rows from 192 source rows
-    {4, 8, 2, 3, 1, 5, 1, 0},     // 6: 2x2 phase conv, 48 rows
-    {4, 8, 2, 4, 1, 5, 1, 0},     // 7: 2x2 phase conv, 64 rows
-    {1, 8, 4, 3, 4, 5, 1, 0},     // 8: Linear / 1x1, 48 rows x 64 columns
-    {1, 8, 4, 3, 2, 5, 1, 0},     // 9: Linear / 1x1, 48 rows x 32 columns
-    {1, 8, 4, 1, 4, 5, 1, 0},     // 10: Linear / 1x1, 16 rows x 64 columns (the time embedding: 9 rows)
-    {1, 4, 2, 9, 1, 4, 1, 0},     // 11: Linear / 1x1, 144 rows x 16 columns (4 waves)
-    {1, 8, 4, 3, 1, 5, 1, 0},     // 12: Linear / 1x1, 48 rows x 16 columns
-    {1, 4, 2, 6, 2, 5, 1, 0},     // 13: Linear / 1x1, 96 rows x 32 columns (4 waves)
-    {9, 9, 1, 3, 2, 5, 1, 0},     // 14: 3x3, 48 rows x 32 columns
-    {9, 9, 1, 4, 2, 5, 1, 0},     // 15: 3x3, 64 rows x 32 columns
-    {9, 9, 2, 3, 1, 5, 1, 0},     // 16: 3x3, 48 rows, two channel blocks per stage (half the barriers)
-    {9, 9, 2, 4, 1, 5, 1, 0},     // 17: 3x3, 64 rows, two channel blocks per stage
-    {9, 9, 1, 12, 1, 3, 1, 0},    // 18: 3x3, 192 rows (three 8x8 images)
-    {4, 8, 2, 12, 1, 3, 1, 0},    // 19: 2x2 phase conv, 192 rows
-    {1, 8, 4, 1, 2, 5, 1, 0},     // 20: Linear / 1x1, 16 rows x 32 columns
-    {9, 8, 4, 3, 1, 3, 1, 1},  // 21: 3x3 balanced (8 waves, 9 items per wave and stage), 48 rows
-    {9, 8, 4, 4, 1, 3, 1, 1},  // 22: 3x3 balanced, 64 rows
-    {9, 8, 4, 3, 1, 4, 1, 1},  // 23: 3x3 balanced, 48 rows, 4-stage ring
-    {9, 8, 4, 1, 1, 3, 4, 1},  // 24: 3x3 stride 2 balanced, 16 output rows from 64 source rows
-    {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
-    {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},     // 25 - 31: unused
-    // independent wave streams (no barrier in the loop; sc = 0): taps / waves / - / row tiles / column tiles / ring depth / source-row multiple
-    {9, 4, 0, 3, 1, 3, 1, 0},  // 32: 3x3, 48 rows, 4 waves
-    {9, 4, 0, 4, 1, 3, 1, 0},  // 33: 3x3, 64 rows, 4 waves
-    {9, 4, 0, 1, 1, 3, 4, 0},  // 34: 3x3 stride 2, 16 output rows from 64 source rows
-    {0, 0, 0, 0, 0, 0, 0, 0},  // 35: unused
-    {4, 4, 0, 3, 1, 4, 1, 0},  // 36: 2x2 phase conv, 48 rows
-    {4, 4, 0, 4, 1, 4, 1, 0},  // 37: 2x2 phase conv, 64 rows
-    {1, 4, 0, 3, 1, 5, 1, 0},  // 38: Linear / 1x1, 48 rows x 16 columns, 4 waves
-    {1, 4, 0, 3, 2, 5, 1, 0},  // 39: Linear / 1x1, 48 rows x 32 columns
-    {1, 4, 0, 3, 4, 5, 1, 0},  // 40: Linear / 1x1, 48 rows x 64 columns
-    {1, 4, 0, 1, 2, 5, 1, 0},  // 41: Linear / 1x1, 16 rows x 32 columns
-    {1, 4, 0, 1, 4, 5, 1, 0},  // 42: Linear / 1x1, 16 rows x 64 columns
-    {1, 8, 0, 3, 1, 2, 1, 0},  // 43: Linear / 1x1, 48 rows x 16 columns, 8 waves
-    {1, 4, 0, 6, 2, 2, 1, 0},  // 44: Linear / 1x1, 96 rows x 32 columns
-    {9, 4, 0, 6, 1, 2, 1, 0},  // 45: 3x3, 96 rows
-    {1, 8, 0, 3, 2, 2, 1, 0},  // 46: Linear / 1x1, 48 rows x 32 columns, 8 waves
+    {9, 9, 1, 3, 1, 10, 1, 0},   // 1: 3x3, 48 rows (three 4x4 images / ...)
+    {9, 9, 1, 4, 1, 10, 1, 0},   // 2: 3x3, 64 rows (one 8x8 image)
+    {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {9, 9, 1, 3, 1, 5, 4, 0},    // 5: 3x3 stride 2, 48 output rows from 192 source rows
+    {4, 8, 2, 3, 1, 5, 1, 0},    // 6: 2x2 phase conv, 48 rows
+    {4, 8, 2, 4, 1, 5, 1, 0},    // 7: 2x2 phase conv, 64 rows
+    {1, 8, 4, 3, 4, 5, 1, 0},    // 8: Linear / 1x1, 48 rows x 64 columns
+    {1, 8, 4, 3, 2, 5, 1, 0},    // 9: Linear / 1x1, 48 rows x 32 columns
+    {1, 8, 4, 1, 4, 5, 1, 0},    // 10: Linear / 1x1, 16 rows x 64 columns
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 8, 4, 3, 1, 5, 1, 0},    // 12: Linear / 1x1, 48 rows x 16 columns
+    {1, 4, 2, 6, 2, 5, 1, 0},    // 13: Linear / 1x1, 96 rows x 32 columns (4 waves)
+    {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    {9, 9, 1, 12, 1, 3, 1, 0},   // 18: 3x3, 192 rows (three 8x8 images)
+    {4, 8, 2, 12, 1, 3, 1, 0},   // 19: 2x2 phase conv, 192 rows
+    {1, 8, 4, 1, 2, 5, 1, 0},    // 20: Linear / 1x1, 16 rows x 32 columns (the time embedding: 9 rows)
+    {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},     // 21 - 31: unused
+    // independent wave streams (no barrier in the loop; sc = 0): taps / waves / - / row tiles / column tiles / ring depth / source-row multiple.
+    // (3x3 and phase forms of it were built and lose to the shared-block kernel: 16.3 / 17.6 us with 4 / 8 waves against 14.7 on the
+    //  4x4-level conv -- with one tap table per wave a wave's own LDS latency is exposed -- so only the 1x1 / Linear forms are kept)
+    {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0},     // 32 - 37
+    {1, 4, 0, 3, 1, 5, 1, 0},    // 38: Linear / 1x1, 48 rows x 16 columns, 4 waves
+    {1, 4, 0, 3, 2, 5, 1, 0},    // 39: Linear / 1x1, 48 rows x 32 columns
+    {1, 4, 0, 3, 4, 5, 1, 0},    // 40: Linear / 1x1, 48 rows x 64 columns
+    {1, 4, 0, 1, 2, 5, 1, 0},    // 41: Linear / 1x1, 16 rows x 32 columns
+    {1, 4, 0, 1, 4, 5, 1, 0},    // 42: Linear / 1x1, 16 rows x 64 columns
+    {1, 8, 0, 3, 1, 2, 1, 0},    // 43: Linear / 1x1, 48 rows x 16 columns, 8 waves
+    {1, 4, 0, 6, 2, 2, 1, 0},    // 44: Linear / 1x1, 96 rows x 32 columns
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 8, 0, 3, 2, 2, 1, 0},    // 46: Linear / 1x1, 48 rows x 32 columns, 8 waves
 };
 constexpr int kNumSkCfgs = sizeof(kSkCfgs) / sizeof(kSkCfgs[0]);
 
@@ -744,45 +734,29 @@ template <typename T> static int sk_dispatch(int cfg, const SkParams& p, int gri
             case 39: return iw_launch<T, IwCfg<1, 4, 3, 2, 5, 1, true>>(p, grid, s);
             case 40: return iw_launch<T, IwCfg<1, 4, 3, 4, 5, 1, true>>(p, grid, s);
             case 44: return iw_launch<T, IwCfg<1, 4, 6, 2, 2, 1, true>>(p, grid, s);
-            case 8: return sk_launch<T, SkCfg<1, 8, 4, 3, 4, 5, 1, false, true>>(p, grid, s);
-            case 9: return sk_launch<T, SkCfg<1, 8, 4, 3, 2, 5, 1, false, true>>(p, grid, s);
-            case 10: return sk_launch<T, SkCfg<1, 8, 4, 1, 4, 5, 1, false, true>>(p, grid, s);
-            case 12: return sk_launch<T, SkCfg<1, 8, 4, 3, 1, 5, 1, false, true>>(p, grid, s);
-            case 13: return sk_launch<T, SkCfg<1, 4, 2, 6, 2, 5, 1, false, true>>(p, grid, s);
-            case 20: return sk_launch<T, SkCfg<1, 8, 4, 1, 2, 5, 1, false, true>>(p, grid, s);
+            case 8: return sk_launch<T, SkCfg<1, 8, 4, 3, 4, 5, 1, true>>(p, grid, s);
+            case 9: return sk_launch<T, SkCfg<1, 8, 4, 3, 2, 5, 1, true>>(p, grid, s);
+            case 10: return sk_launch<T, SkCfg<1, 8, 4, 1, 4, 5, 1, true>>(p, grid, s);
+            case 12: return sk_launch<T, SkCfg<1, 8, 4, 3, 1, 5, 1, true>>(p, grid, s);
+            case 13: return sk_launch<T, SkCfg<1, 4, 2, 6, 2, 5, 1, true>>(p, grid, s);
+            case 20: return sk_launch<T, SkCfg<1, 8, 4, 1, 2, 5, 1, true>>(p, grid, s);
             default: return set_error(MVLDM_ERR_UNSUPPORTED, "igemm: tile 15: configuration %d does not take two sources", cfg);
         }
     }
     switch (cfg) {
         case 1: return sk_launch<T, SkCfg<9, 9, 1, 3, 1, 10, 1>>(p, grid, s);
         case 2: return sk_launch<T, SkCfg<9, 9, 1, 4, 1, 10, 1>>(p, grid, s);
-        case 3: return sk_launch<T, SkCfg<9, 9, 1, 9, 1, 5, 1>>(p, grid, s);
-        case 4: return sk_launch<T, SkCfg<9, 9, 1, 1, 1, 10, 4>>(p, grid, s);
         case 5: return sk_launch<T, SkCfg<9, 9, 1, 3, 1, 5, 4>>(p, grid, s);
         case 6: return sk_launch<T, SkCfg<4, 8, 2, 3, 1, 5, 1>>(p, grid, s);
         case 7: return sk_launch<T, SkCfg<4, 8, 2, 4, 1, 5, 1>>(p, grid, s);
         case 8: return sk_launch<T, SkCfg<1, 8, 4, 3, 4, 5, 1>>(p, grid, s);
         case 9: return sk_launch<T, SkCfg<1, 8, 4, 3, 2, 5, 1>>(p, grid, s);
         case 10: return sk_launch<T, SkCfg<1, 8, 4, 1, 4, 5, 1>>(p, grid, s);
-        case 11: return sk_launch<T, SkCfg<1, 4, 2, 9, 1, 4, 1>>(p, grid, s);
         case 12: return sk_launch<T, SkCfg<1, 8, 4, 3, 1, 5, 1>>(p, grid, s);
         case 13: return sk_launch<T, SkCfg<1, 4, 2, 6, 2, 5, 1>>(p, grid, s);
-        case 14: return sk_launch<T, SkCfg<9, 9, 1, 3, 2, 5, 1>>(p, grid, s);
-        case 15: return sk_launch<T, SkCfg<9, 9, 1, 4, 2, 5, 1>>(p, grid, s);
-        case 16: return sk_launch<T, SkCfg<9, 9, 2, 3, 1, 5, 1>>(p, grid, s);
-        case 17: return sk_launch<T, SkCfg<9, 9, 2, 4, 1, 5, 1>>(p, grid, s);
         case 18: return sk_launch<T, SkCfg<9, 9, 1, 12, 1, 3, 1>>(p, grid, s);
         case 19: return sk_launch<T, SkCfg<4, 8, 2, 12, 1, 3, 1>>(p, grid, s);
         case 20: return sk_launch<T, SkCfg<1, 8, 4, 1, 2, 5, 1>>(p, grid, s);
-        case 21: return sk_launch<T, SkCfg<9, 8, 4, 3, 1, 3, 1, true>>(p, grid, s);
-        case 22: return sk_launch<T, SkCfg<9, 8, 4, 4, 1, 3, 1, true>>(p, grid, s);
-        case 23: return sk_launch<T, SkCfg<9, 8, 4, 3, 1, 4, 1, true>>(p, grid, s);
-        case 24: return sk_launch<T, SkCfg<9, 8, 4, 1, 1, 3, 4, true>>(p, grid, s);
-        case 32: return iw_launch<T, IwCfg<9, 4, 3, 1, 3, 1>>(p, grid, s);
-        case 33: return iw_launch<T, IwCfg<9, 4, 4, 1, 3, 1>>(p, grid, s);
-        case 34: return iw_launch<T, IwCfg<9, 4, 1, 1, 3, 4>>(p, grid, s);
-        case 36: return iw_launch<T, IwCfg<4, 4, 3, 1, 4, 1>>(p, grid, s);
-        case 37: return iw_launch<T, IwCfg<4, 4, 4, 1, 4, 1>>(p, grid, s);
         case 38: return iw_launch<T, IwCfg<1, 4, 3, 1, 5, 1>>(p, grid, s);
         case 39: return iw_launch<T, IwCfg<1, 4, 3, 2, 5, 1>>(p, grid, s);
         case 40: return iw_launch<T, IwCfg<1, 4, 3, 4, 5, 1>>(p, grid, s);
@@ -790,7 +764,6 @@ template <typename T> static int sk_dispatch(int cfg, const SkParams& p, int gri
         case 42: return iw_launch<T, IwCfg<1, 4, 1, 4, 5, 1>>(p, grid, s);
         case 43: return iw_launch<T, IwCfg<1, 8, 3, 1, 2, 1>>(p, grid, s);
         case 44: return iw_launch<T, IwCfg<1, 4, 6, 2, 2, 1>>(p, grid, s);
-        case 45: return iw_launch<T, IwCfg<9, 4, 6, 1, 2, 1>>(p, grid, s);
         case 46: return iw_launch<T, IwCfg<1, 8, 3, 2, 2, 1>>(p, grid, s);
         default: return set_error(MVLDM_ERR_ARG, "igemm: tile 15: bad configuration %d", cfg);
     }
@@ -843,25 +816,35 @@ bool skinny_applicable(const mvldm_igemm_desc& d) {
     return true;
 }
 
-// the rule (no plan-time tuning): the widest row tile that keeps >= ~200 workgroups
+// the rule (no plan-time tuning): the configuration that won the shape class in tools/skinny_bench.py (profiles/r05_skinny_bench.json)
 static int sk_choose(const mvldm_igemm_desc& d) {
-    int best = 0;
-    double best_cost = 1e300;
-    for (int c = 1; c < kNumSkCfgs; ++c) {
-        const SkinnyCfgInfo& k = kSkCfgs[c];
-        if (!sk_cfg_fits(k, d)) continue;
-        const SkGeom g = sk_geom(d);
-        const int G = k.mt * 16 / (g.h_out * g.w_out);
-        const int mg = (g.n_img + G - 1) / G, ngr = (d.n_pad / 16 + k.nt - 1) / k.nt;
-        const double wgs = (double)mg * ngr;
-        // per-workgroup operand bytes into the CU (weights + activations), rounds of 256 workgroups
-        const double kbytes = (double)d.k_pad * 2.0;
-        const double per_wg = kbytes * k.nt * 16 + (double)G * g.h_in * g.w_in * (d.c0 + d.c1) * 2.0;
-        const double rounds = std::ceil(wgs / 256.0);
-        const double cost = rounds * per_wg;
-        if (cost < best_cost) { best_cost = cost; best = c; }
+    const SkGeom g = sk_geom(d);
+    const int hw = g.h_out * g.w_out, taps = d.ksize * d.ksize, M = g.n_img * hw;
+    int pref[6] = {0, 0, 0, 0, 0, 0};
+    if (taps == 9) {
+        if (d.stride == 2) { pref[0] = 5; }
+        else if (hw > 48) { pref[0] = g.n_img >= 2 ? 18 : 2; pref[1] = 2; pref[2] = 18; }
+        else { pref[0] = 1; pref[1] = 18; pref[2] = 2; }
+    } else if (taps == 4) {
+        if (hw > 48) { pref[0] = g.n_img >= 2 ? 19 : 7; pref[1] = 7; pref[2] = 19; }
+        else { pref[0] = 6; pref[1] = 7; pref[2] = 19; }
+    } else {
+        if (M <= 16) { pref[0] = 20; pref[1] = 41; pref[2] = 10; }
+        else if (M <= 160) {
+            if (d.n_pad >= 2560) { pref[0] = 8; pref[1] = 40; }
+            else { pref[0] = 38; pref[1] = 12; }
+            pref[2] = 9;
+        } else {
+            if (d.n_pad <= 1280) { pref[0] = 44; pref[1] = 13; pref[2] = 9; }
+            else { pref[0] = 8; pref[1] = 40; }
+        }
+        pref[4] = 12; pref[5] = 8;
     }
-    return best;
+    for (int c : pref)
+        if (c > 0 && c < kNumSkCfgs && sk_cfg_fits(kSkCfgs[c], d)) return c;
+    for (int c = 1; c < kNumSkCfgs; ++c)
+        if (sk_cfg_fits(kSkCfgs[c], d)) return c;
+    return 0;
 }
 
 int skinny_run(const mvldm_igemm_desc& d, hipStream_t s) {

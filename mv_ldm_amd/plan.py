@@ -205,7 +205,7 @@ class Builder:
             tile, splitk = _PIN_TILE(), 1        # (test knob MVLDM_IGEMM_TILE: one tile, one K pass for every 16-bit block-major launch, see _PIN_TILE)
         m = n * ho * wo
         can_sk = self.skinny and skinny_candidate(pw, m, c0, c1, upsample, x.dtype)
-        if tile == 0 and can_sk and _SKINNY_RULE and m <= _SKINNY_RULE_ROWS:
+        if tile == 0 and can_sk and skinny_rule(m, pw.n_pad):
             tile = 15                            # the rule: launches of a few hundred rows stream their weights (csrc/skinny.hip)
         d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
         d.dst_ld = out.shape[-1] if out.shape[-1] != n_dst else 0
@@ -274,7 +274,7 @@ class Builder:
         d.epilogue, d.act_dtype, d.dst_dtype = L.EPI_NONE, dt(x), dt(out)
         m = n * h * w
         can_sk = self.skinny and skinny_candidate(pw, m, c0, 0, False, x.dtype)
-        if tile == 0 and can_sk and _SKINNY_RULE and m <= _SKINNY_RULE_ROWS:
+        if tile == 0 and can_sk and skinny_rule(m, pw.n_pad):
             tile = 15
         d.splitk, d.tile, d.out_scale = splitk, tile, 1.0
         d.dst_ld = 0
@@ -559,13 +559,20 @@ _SMALL_TILES = tuple(int(t) for t in os.environ.get("MVLDM_TUNE_SMALL_TILES", "0
 # ---- igemm tile 15 (csrc/skinny.hip): the skinny-M weight-streaming kernel.  It reads the FRAGMENT-ORDER copy of the packed weight
 # (`PackedWeight.skinny()`, made on first use), so a choice of tile 15 swaps the descriptor's weight pointer and sets k_order = 2.
 # Candidates: 16-bit block-major convs / Linears of at most MVLDM_SKINNY_ROWS output rows whose channel counts are multiples of 64.
-# MVLDM_SKINNY=0 keeps it out of the plans (A/B knob); MVLDM_SKINNY_RULE=1 makes it the RULE for launches of at most
-# MVLDM_SKINNY_RULE_ROWS rows (used when plan-time tuning is off; with tuning on it is one more candidate, timed like the tiles).
+# With plan-time tuning on it is one more candidate, timed like the tiles in every configuration the library accepts; with tuning off
+# (MVLDM_AUTOTUNE=0) it is the RULE for the shape classes it won in tools/skinny_bench.py (profiles/r05_skinny_bench.json): launches of at
+# most 160 rows, and of at most 1152 rows when the packed width is at most 1280 (the wide QKV / GEGLU / FF projections of the 8x8 level
+# re-read their activation block once per 16-column tile and stay with the tiled kernels).  MVLDM_SKINNY=0 keeps it out of the plans (A/B).
 _SKINNY = os.environ.get("MVLDM_SKINNY", "1") != "0"
 _SKINNY_ROWS = int(os.environ.get("MVLDM_SKINNY_ROWS", "2304"))
-_SKINNY_RULE = os.environ.get("MVLDM_SKINNY_RULE", "0") == "1"
-_SKINNY_RULE_ROWS = int(os.environ.get("MVLDM_SKINNY_RULE_ROWS", "576"))
-_SKINNY_CFGS = tuple(int(c) for c in os.environ.get("MVLDM_SKINNY_CFGS", "0,1,2,5,6,7,8,9,10,12,13,18,19,20,32,33,34,36,37,38,39,40,41,42,43,44,45,46").split(","))
+_SKINNY_CFGS = tuple(int(c) for c in os.environ.get("MVLDM_SKINNY_CFGS", "0,1,2,5,6,7,8,9,10,12,13,18,19,20,38,39,40,41,42,43,44,46").split(","))
+
+
+def skinny_rule(rows: int, n_pad: int) -> bool:
+    """rule-based choice of tile 15 (read per call: tests set the variables with monkeypatch)"""
+    if os.environ.get("MVLDM_AUTOTUNE", "1") != "0" or os.environ.get("MVLDM_SKINNY_RULE", "1") == "0":
+        return False
+    return rows <= 160 or (rows <= 1152 and n_pad <= 1280)
 
 
 def skinny_candidate(pw: PackedWeight, rows: int, c0: int, c1: int, upsample, dtype) -> bool:
