@@ -123,6 +123,10 @@ int mvldm_pack_weight(const float* src, void* dst, int n_out, int c_in, int ksiz
  * pack (`geglu` != 0: rows alternate [32 value | 32 gate]) where tiles (2q, 2q+1) are the value / gate rows of output columns
  * 16 q .. 16 q + 15.  Same byte count as `packed`.  replaces: nothing in the reference (a load-time transform like mvldm_pack_weight). */
 int mvldm_pack_skinny(const void* packed, void* dst, int n_pad, int k_pad, int geglu, int dtype, mvldm_stream_t stream);
+/* Host-side query (no GPU work): the tile-15 configuration the library's rule picks for the problem `d` describes (pointers may be the
+ * K-major ones: only shapes, dtypes, alignment and the epilogue are looked at), or 0 when tile 15 cannot compute it (an image larger than
+ * a workgroup's row tiles, f32, channels that are not multiples of 64 ...).  Plan builders ask before they commit an op to tile 15. */
+int mvldm_igemm_skinny_config(const mvldm_igemm_desc* d);
 
 /* The same transform for MANY weights in one launch (round 3): after an optimizer step the training path re-packs every
  * trained weight (forward + data-gradient packs, ~380 of them) -- as one launch per pack these are latency-bound (7 ms for

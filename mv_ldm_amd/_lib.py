@@ -188,6 +188,7 @@ SIGNATURES = {
     "mvldm_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
     "mvldm_pack_weight": (C.c_int, [vp, vp] + [C.c_int] * 12 + [vp]),
     "mvldm_pack_skinny": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "mvldm_igemm_skinny_config": (C.c_int, [C.POINTER(IgemmDesc)]),
     "mvldm_pack_job_prepare": (C.c_int, [C.POINTER(PackJob), C.c_int]),
     "mvldm_pack_weight_batch": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "mvldm_groupnorm_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp, vp, vp]),

@@ -922,6 +922,15 @@ int skinny_run(const mvldm_igemm_desc& d, hipStream_t s) {
 
 using namespace mvldm;
 
+extern "C" int mvldm_igemm_skinny_config(const mvldm_igemm_desc* d) {
+    if (!d) return 0;
+    mvldm_igemm_desc t = *d;
+    t.k_order = 2;                // the question is about the problem, not about which pack the caller holds at the moment
+    if (!t.weight) t.weight = t.src0;
+    if (!skinny_applicable(t)) return 0;
+    return sk_choose(t);
+}
+
 extern "C" int mvldm_pack_skinny(const void* packed, void* dst, int n_pad, int k_pad, int geglu, int dtype, mvldm_stream_t stream) {
     MVLDM_REQUIRE(packed && dst, "pack_skinny: null pointer");
     MVLDM_REQUIRE(dtype == MVLDM_BF16 || dtype == MVLDM_F16, "pack_skinny: 16-bit types only");

@@ -205,11 +205,12 @@ class Builder:
             tile, splitk = _PIN_TILE(), 1        # (test knob MVLDM_IGEMM_TILE: one tile, one K pass for every 16-bit block-major launch, see _PIN_TILE)
         m = n * ho * wo
         can_sk = self.skinny and skinny_candidate(pw, m, c0, c1, upsample, x.dtype)
-        if tile == 0 and can_sk and skinny_rule(m, pw.n_pad):
-            tile = 15                            # the rule: launches of a few hundred rows stream their weights (csrc/skinny.hip)
         d.splitk, d.tile, d.out_scale = splitk, tile, out_scale
         d.dst_ld = out.shape[-1] if out.shape[-1] != n_dst else 0
         d.k_order = pw.k_order
+        can_sk = can_sk and x.is_cuda and L.load().mvldm_igemm_skinny_config(C.byref(d)) > 0      # (an image may be larger than the kernel's row tiles)
+        if tile == 0 and can_sk and skinny_rule(m, pw.n_pad):
+            tile = d.tile = 15                   # the rule: launches of a few hundred rows stream their weights (csrc/skinny.hip)
         if (tile & 63) == 15:
             d.weight, d.k_order = ptr(pw.skinny()), 2
         elif can_sk and self.record and tile == 0:
@@ -274,11 +275,12 @@ class Builder:
         d.epilogue, d.act_dtype, d.dst_dtype = L.EPI_NONE, dt(x), dt(out)
         m = n * h * w
         can_sk = self.skinny and skinny_candidate(pw, m, c0, 0, False, x.dtype)
-        if tile == 0 and can_sk and skinny_rule(m, pw.n_pad):
-            tile = 15
         d.splitk, d.tile, d.out_scale = splitk, tile, 1.0
         d.dst_ld = 0
         d.k_order = 1
+        can_sk = can_sk and x.is_cuda and L.load().mvldm_igemm_skinny_config(C.byref(d)) > 0
+        if tile == 0 and can_sk and skinny_rule(m, pw.n_pad):
+            tile = d.tile = 15
         if (tile & 63) == 15:
             d.weight, d.k_order = ptr(pw.skinny()), 2
         elif can_sk and self.record and tile == 0:

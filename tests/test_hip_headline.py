@@ -159,7 +159,7 @@ def test_rule_based_tiles_match_the_tuned_plan(models, monkeypatch, dtype):
             outs[mode] = pipe._read_state(st, b, v_t).cpu()
         tiles[mode] = [t for t in st["plan"].tiles if t is not None]
         pipe._plans.clear()
-    assert all(t == 0 for t in tiles["0"])                          # rules only
+    assert all(t in (0, 15) for t in tiles["0"])                    # rules only (15: the shape rule of the skinny weight-streaming kernel, plan.skinny_rule)
     if dtype != torch.float32:
         assert any(t != 0 for t in tiles["1"]) or not P._TUNE_CACHE  # the tuned plan froze at least one tile (f32 is never tuned)
     e = record_err(f"tuned_vs_rules/{str(dtype)[6:]}", rel_err(outs["1"], outs["0"]))
