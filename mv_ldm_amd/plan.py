@@ -487,6 +487,7 @@ class Builder:
 # MVLDM_TUNE_TILES=0,2,9,... restricts the candidates (the small 64x64 / 32x64 tiles only ever win below ~4 scenes: +2 % at b = 1).
 _TUNE_CACHE = {}
 _WGRAD_CACHE = {}
+_VALIDATED = set()         # igemm cache entries this process has launched once (entries loaded from a file are trial-launched before use)
 _TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) if os.environ.get("MVLDM_TUNE_TILES") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)
 
 
@@ -653,8 +654,26 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
             t_best, tile_best, sk_best = min(results, key=lambda r: r[0])
             best = [tile_best, sk_best] if t_best < 0.97 * t_rule else [0, None]
             _TUNE_CACHE[key] = best
+            _VALIDATED.add(key)
             timed += 1
         tile, sk = _unpack_choice(best)
+        if tile != 0 and key not in _VALIDATED:
+            # an entry from a file / another rank: this build's tile must accept the problem (one trial launch), else the rule stands --
+            # a plan that fails at run time is worse than an untuned op
+            trial = L.Op()
+            C.memmove(C.byref(trial), C.byref(op), C.sizeof(L.Op))
+            trial.u.igemm.tile = tile
+            if sk is not None:
+                trial.u.igemm.splitk = sk
+            if (tile & 63) == 15:
+                if sk_pw is None:
+                    tile, sk = 0, None
+                else:
+                    trial.u.igemm.weight, trial.u.igemm.k_order = sk_pw.skinny().data_ptr(), 2
+            if tile != 0 and lib.mvldm_op_run(C.byref(trial), stream) != 0:
+                tile, sk = 0, None
+                _TUNE_CACHE[key] = [0, None]
+            _VALIDATED.add(key)
         d.tile = tile
         if sk is not None:
             d.splitk = sk
@@ -693,7 +712,7 @@ def autotune_wgrad(ops, iters: int = 3) -> int:
         if d.act_dtype == L.F32 or (d.accumulate >> 8) & 3:
             continue
         key = (d.c0, d.c1, d.n_img, d.h_in, d.w_in, d.h_out, d.w_out, d.ksize, d.stride, d.pad, d.upsample, d.n_out, d.dy_ld, d.act_dtype,
-               int(d.workspace_bytes))          # (the workspace bounds the split count, hence which form wins)
+               int(d.workspace_bytes), d.accumulate & 1)      # (store-first one-split Linears take the direct path: another problem than the accumulating op)          # (the workspace bounds the split count, hence which form wins)
         best = _WGRAD_CACHE.get(key)
         if best is None:
             trial = L.Op()

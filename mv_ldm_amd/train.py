@@ -98,8 +98,8 @@ class FlatParams:
 
     def wait_readers(self):
         """call before WRITING `flat` in place on the current stream: a weight re-pack launched ahead on the trainer's side stream
-        (`MVLDMTrainer._repack_ahead`) may still be READING it.  The optimizer step, `EMAWeights.applied` (entry and exit) and the
-        checkpoint loaders go through here; without it the ~5 ms packing launch could pick up a mix of live and averaged / updated
+        (`MVLDMTrainer._repack_ahead`) may still be READING it.  The optimizer step, `EMAWeights.applied` (entry and exit) and
+        `MVLDMTrainer.load_denoiser_state_dict` go through here; without it the ~5 ms packing launch could pick up a mix of live and averaged / updated
         weights, and because the plan is already marked current the bad packs would never be redone."""
         ev = self.__dict__.get("_read_event")
         if ev is not None and torch.cuda.is_available():
@@ -1272,6 +1272,16 @@ class MVLDMTrainer:
         self._stage_part(tp, 0, part)
         return tp
 
+    def load_denoiser_state_dict(self, state_dict, strict: bool = True):
+        """`denoiser.load_state_dict` for a trainer that is alive: the flat parameter views are written in place, so a re-pack still
+        reading them on the side stream is waited for first, and every recorded plan re-packs before its next run (ADVICE round 4:
+        a plain `denoiser.load_state_dict` right after a window could leave mixed packs that were never redone)."""
+        self.flat.wait_readers()
+        out = self.denoiser.load_state_dict(state_dict, strict=strict)
+        self._weights_gen += 1
+        self.flat.bump()
+        return out
+
     def _fresh(self, tp: TrainPlan):
         ev = tp.__dict__.pop("_repack_event", None)
         if ev is not None:                           # re-packed ahead of time on the side stream (`_repack_ahead`)
@@ -1346,6 +1356,17 @@ class MVLDMTrainer:
         main = torch.cuda.current_stream()
         if self.__dict__.get("_enc_stream") is None:
             self._enc_stream = torch.cuda.Stream(device=self.flat.flat.device)
+        # The encoder has ONE set of plan buffers (vae.py: source copy, arena, output) and `_busy_event` only orders side-stream use
+        # before LATER main-stream use.  The other direction: a main-stream encode of THIS window (`_prepare_window` after a prefetch
+        # mismatch, the first window, `prepare()`), and any main-stream copies that filled the next batches' tensors, must have finished
+        # before the side stream touches the same buffers -- the event `training_window` records right after staging its parts (before
+        # the plan launch: the overlap with the backward pass stays).  (with a graph-replayed plan the host is far enough
+        # ahead for the side-stream encode to overwrite a main-stream encode still in flight.)
+        staged = self.__dict__.get("_staged_event")
+        if staged is not None:
+            self._enc_stream.wait_event(staged)
+        else:
+            self._enc_stream.wait_stream(main)
         with torch.cuda.stream(self._enc_stream):
             parts, lats = self._prepare_window(batches, choices)
             for t in lats:
@@ -1353,7 +1374,7 @@ class MVLDMTrainer:
             ev = torch.cuda.Event()
             ev.record(self._enc_stream)
         self.autoencoder.__dict__["_busy_event"] = ev          # any other user of the encoder's plans (a validation sample on the main stream) waits for it
-        self._prefetched = dict(ids=self._batches_key(batches), parts=parts, lats=lats, event=ev)
+        self._prefetched = dict(ids=self._batches_key(batches), choices=self._choices_key(choices), parts=parts, lats=lats, event=ev)
 
     @staticmethod
     def _batches_key(batches):
@@ -1371,13 +1392,28 @@ class MVLDMTrainer:
             key.append(tuple(k))
         return tuple(key)
 
-    def _take_prefetched(self, batches):
+    @staticmethod
+    def _choices_key(choices):
+        """the explicit draws a window was prepared with (index, second, relative_coin, unconditional, noise, timestep, encode_noise per
+        micro-batch): a prefetched window is only taken when the caller passes the same ones again"""
+        if choices is None:
+            return None
+        key = []
+        for ch in choices:
+            k = []
+            for name in sorted(ch or {}):
+                v = ch[name]
+                k.append((name, ("t", id(v), v.data_ptr(), v._version, tuple(v.shape)) if torch.is_tensor(v) else repr(v)))
+            key.append(tuple(k))
+        return tuple(key)
+
+    def _take_prefetched(self, batches, choices=None):
         pre = self.__dict__.pop("_prefetched", None)
         if pre is None:
             return None
         torch.cuda.current_stream().wait_event(pre["event"])
-        if pre["ids"] != self._batches_key(batches):
-            return None               # prepared for other batches (or the same objects, modified since): encode what came (the draw order is the caller's then)
+        if pre["ids"] != self._batches_key(batches) or pre["choices"] != self._choices_key(choices):
+            return None               # prepared for other batches / other explicit draws (or the same objects, modified since): encode what came
         return pre["parts"], pre["lats"]
 
     def training_window(self, batches: Sequence[dict], choices: Optional[Sequence[dict]] = None, prefetch=None) -> torch.Tensor:
@@ -1392,7 +1428,7 @@ class MVLDMTrainer:
         critical path (`_start_prefetch`)."""
         acc = self.cfg.accumulate_grad_batches
         assert len(batches) == acc and self.micro % acc == 0, "training_window takes one full accumulation window at its start"
-        parts, lats = self._take_prefetched(batches) or self._prepare_window(batches, choices)
+        parts, lats = self._take_prefetched(batches, choices) or self._prepare_window(batches, choices)
         parts = [self._finish_part(p_, lat) for p_, lat in zip(parts, lats)]
         hw = {tuple(p_["lat"].shape[-2:]) for p_ in parts}
         assert len(hw) == 1, "one accumulation window, one latent resolution"
@@ -1408,6 +1444,8 @@ class MVLDMTrainer:
             tp_.loss.zero_()
         for i, p_ in enumerate(parts):
             self._stage_part(tp, i, p_)
+        if torch.cuda.is_available():
+            self._staged_event = torch.cuda.current_stream().record_event()      # (what `_start_prefetch` orders its side stream after)
         self._fresh(tp)
         if self.opt.collective:
             self._run_overlapped(tp)

@@ -628,3 +628,24 @@ def test_encoding_the_next_window_ahead_changes_nothing_but_the_time(golden):
         for k_ in ("extrinsics", "intrinsics"):
             bb[side][k_].copy_(b1[side][k_])
     assert [float(x) for x in tr.training_window([bb, bb], ch)] == want
+    # ... and the same batches prepared with OTHER explicit draws than the ones the window is then run with (the key
+    # covered the batch tensors only, the parts built from the prefetch-time choices were used silently): encoded again
+    tr = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3))
+    other = [hip_choices(g9_case(g, 0)[1])] * 2
+    tr._start_prefetch([b1, b1], other)
+    assert [float(x) for x in tr.training_window([b1, b1], ch)] == want
+    # ... while the SAME draws are taken from the prefetch (the event recorded after staging orders the side stream behind the
+    # main stream: a graph-replayed window right before it must not be overtaken)
+    tr = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3))
+    first = [float(x) for x in tr.training_window([b1, b1], ch, prefetch=([b1, b1], ch))]
+    assert first == want and tr.__dict__.get("_prefetched") is not None and tr.__dict__.get("_staged_event") is not None
+    ref = build_trainer(g, torch.float32, optimizer_cfg=OptimizerCfg(lr=1e-3))
+    ref.training_window([b1, b1], ch)
+    assert [float(x) for x in tr.training_window([b1, b1], ch)] == [float(x) for x in ref.training_window([b1, b1], ch)]
+    assert tr.__dict__.get("_prefetched") is None
+    # a trainer-level state-dict load waits for the side-stream re-pack and makes every plan re-pack
+    sd = {k: v.clone() for k, v in ref.denoiser.state_dict().items()}
+    gen0 = tr._weights_gen
+    tr.load_denoiser_state_dict(sd)
+    assert tr._weights_gen == gen0 + 1
+    assert [float(x) for x in tr.training_window([b1, b1], ch)] == [float(x) for x in ref.training_window([b1, b1], ch)]
