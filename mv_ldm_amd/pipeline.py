@@ -385,3 +385,45 @@ class MVLDMPipeline:
                 z = None if step_noise is None else step_noise[i]
                 x_t = self.step(self.denoiser, x_t, t, ctx_in, rays, mask, step_generator=step_generator, step_noise=z)
         return (self.last_stage_decode(x_t) if decode else None), x_t
+
+
+def install_fused_sampler(wrapper, *, num_inference_steps: Optional[int] = None):
+    """One call on a constructed reference `DiffusionWrapper` (level A of INTEGRATION.md: its denoiser / scheduler / autoencoder came
+    out of the registries as this package's classes) that makes `wrapper.sample(batch)` (`diffusion_wrapper.py:455-490`) run the FUSED
+    sampler -- both CFG passes in one forward, the DDIM update inside the captured graph -- without editing `DiffusionWrapper`:
+
+        wrapper = DiffusionWrapper(...)                      # unchanged reference code
+        mv_ldm_amd.pipeline.install_fused_sampler(wrapper)   # once, after construction / checkpoint load
+
+    `sample` keeps the reference's contract: it returns `(images [b, v_t, 3, H, W] in [0, 1], batch)`, reads `model_cfg.use_cfg`,
+    `model_cfg.cfg_scale`, `model_cfg.use_ema_sampling` (then `wrapper.ema.module` is the denoiser) and the scheduler's current
+    `timesteps` at every call, and draws x_T on the CPU generator like `:473`.  `wrapper.step` and everything else stay the reference's.
+    Returns the pipeline object that now backs `sample` (its recorded plans live there; `wrapper._mvldm_pipeline`)."""
+    mc = wrapper.model_cfg
+
+    def _denoiser():
+        if getattr(mc, "use_ema_sampling", False) and getattr(wrapper, "ema", None) is not None:
+            return getattr(wrapper.ema, "module", wrapper.ema)
+        return wrapper.denoiser
+
+    if not isinstance(_denoiser(), MultiViewUNet):
+        raise TypeError("install_fused_sampler: wrapper.denoiser is not mv_ldm_amd.mvunet.MultiViewUNet -- register the HIP classes in the "
+                        "reference's DENOISER / SCHEDULER / AUTOENCODERS registries first (INTEGRATION.md level A)")
+    pipe = MVLDMPipeline(_denoiser(), wrapper.autoencoder, wrapper.scheduler,
+                         SamplerCfg(bool(mc.use_cfg), float(mc.cfg_scale), int(num_inference_steps or len(wrapper.scheduler.timesteps) or 50)))
+
+    def sample(batch):
+        den = _denoiser()
+        if den is not pipe.denoiser:                       # EMA switched on / off since the last call
+            pipe.denoiser = den
+            pipe._plans.clear()
+        cfg = (bool(mc.use_cfg), float(mc.cfg_scale))
+        if cfg != (pipe.cfg.use_cfg, pipe.cfg.cfg_scale):
+            pipe.cfg = SamplerCfg(cfg[0], cfg[1], pipe.cfg.num_inference_steps)
+            pipe._plans.clear()
+        images, _ = pipe.sample({"context": batch["context"], "target": batch["target"]})
+        return images, batch
+
+    wrapper.sample = sample
+    wrapper._mvldm_pipeline = pipe
+    return pipe

@@ -55,7 +55,8 @@ def test_mvunet_with_standard_blocks_vs_reference_golden(golden, dtype):
     x, t = torch.from_numpy(g["unet_x"]).cuda(), torch.from_numpy(g["unet_t"]).cuda()
     with mv_ldm_amd.compute_dtype(dtype):
         y, yw = m(x, t), m.forward_walk(x, t)
-    assert rel_err(y.cpu(), g["unet_y"]) < TOL_MODEL[dtype] and rel_err(yw.cpu(), g["unet_y"]) < TOL_MODEL[dtype]
+    from conftest import record_err
+    assert record_err(f"g10_unet/{str(dtype)[6:]}", max(rel_err(y.cpu(), g["unet_y"]), rel_err(yw.cpu(), g["unet_y"]))) < TOL_MODEL[dtype]
 
 
 def test_ray_encodings_vs_reference_golden(golden):
