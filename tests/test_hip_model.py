@@ -17,13 +17,14 @@ from seeded import load_seeded, random_cameras
 
 pytestmark = pytest.mark.gpu
 
-# 16-bit tolerances = 2 x the maximum measured on MI355X (tests/golden/measured_errors_r04.json, written by MVLDM_TEST_REPORT: g1_block,
+# 16-bit tolerances = 2 x the maximum measured on MI355X (tests/golden/measured_errors_r04.json / _r05.json, written by MVLDM_TEST_REPORT: g1_block,
 # g4_model, g11_*), f32 = the north-star 1e-3 or tighter: a 1 % regression of a 16-bit kernel fails these, the round numbers of rounds 1-3 did not
 TOL_BLOCK = {torch.float32: 2e-4, torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}      # G1: measured 5.8e-7 / 7.2e-4 / 5.8e-3
 TOL_G4 = {torch.float32: 1e-3, torch.float16: 3.7e-3, torch.bfloat16: 2.9e-2}         # G4: measured 1.6e-6 / 1.8e-3 / 1.4e-2
-TOL_MODEL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}          # G5 step / sample (x 2): PLACEHOLDER until measured
-TOL_VAE = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}
-TOL_VAE_FULL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}
+# round 5 (tests/golden/measured_errors_r05.json): the last round-number tolerances are gone too
+TOL_MODEL = {torch.float32: 1e-3, torch.float16: 3.2e-3, torch.bfloat16: 2.5e-2}      # G5 step / sample (x 2), full topology: measured 1.5e-6 / 1.55e-3 / 1.2e-2
+TOL_VAE = {torch.float32: 1e-3, torch.float16: 3.6e-3, torch.bfloat16: 2.8e-2}        # reduced-width VAE: measured 1.6e-6 / 1.76e-3 / 1.4e-2
+TOL_VAE_FULL = {torch.float32: 1e-4, torch.float16: 3.2e-3, torch.bfloat16: 2.6e-2}   # SD-2.1-width decoder, one 256 x 256 view: measured 2.8e-6 / 1.59e-3 / 1.28e-2
 TOL_G11 = {torch.float32: 5e-4, torch.float16: 2.3e-3, torch.bfloat16: 2.2e-2}        # whole samples; measured 1.8e-4 (the fixture's f16 storage) / 1.1e-3 / 1.06e-2
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 IDS = ["f32", "bf16", "f16"]

@@ -13,7 +13,7 @@ from seeded import load_seeded
 pytestmark = pytest.mark.gpu
 GRAD_ENABLED = False      # tests/conftest.py::_grad_mode: no autograd graphs in this module
 TOL_BLOCK = {torch.float32: 2e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}
-TOL_MODEL = {torch.float32: 1e-3, torch.float16: 8e-3, torch.bfloat16: 5e-2}
+TOL_MODEL = {torch.float32: 1e-3, torch.float16: 2.2e-3, torch.bfloat16: 1.7e-2}      # G10 UNet: 2 x measured on MI355X (1e-6 / 1.08e-3 / 8.5e-3, tests/golden/measured_errors_r05.json)
 DTYPES, IDS = [torch.float32, torch.bfloat16, torch.float16], ["f32", "bf16", "f16"]
 
 
