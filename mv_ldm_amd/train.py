@@ -947,6 +947,13 @@ class DistributedOptimizer:
         self.norm = torch.zeros(4, dtype=torch.float32, device=dev)
         self._update, self._sumsq, self._clip = update or _hip_adamw, sumsq or _hip_sumsq, clip or _hip_clip
         self._pending = []
+        # communication accounting (bench.py --train prints it per rank; tests read the events): bytes handed to reduce-scatter /
+        # all-gather, the device time the compute stream spends WAITING for outstanding collectives (`exposed`), and per bucket the
+        # compute-stream event at which its reduce was enqueued (to check that it went out before the backward pass had finished)
+        self.bytes_reduced = 0
+        self.bytes_gathered = 0
+        self._exposed = []            # (start event, end event) pairs around every wait for collectives on the compute stream
+        self.bucket_events = {}       # bucket -> event recorded on the compute stream when its reduce was enqueued (last step)
 
     # ---- learning rate (LinearLR: factor after `step_count` scheduler steps) ----
     def lr(self) -> float:
@@ -963,15 +970,41 @@ class DistributedOptimizer:
         a, b = self.buckets[k]
         oa, ob = self.owned[k]
         g = self.flat.grad
+        self.bytes_reduced += (b - a) * 4
+        if g.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.bucket_events[k] = ev
         if dist.get_backend(self.group) == "gloo":      # CPU tests: gloo has no reduce-scatter; the owned slice of an all-reduce is the same thing
             self._pending.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:                                           # RCCL, in place: recvbuff == sendbuff + rank * recvcount
             self._pending.append(dist.reduce_scatter_tensor(g[oa:ob], g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
+        timed = bool(self._pending) and self.flat.grad.is_cuda
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._pending:
             w.wait()
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._exposed.append((e0, e1))
         self._pending = []
+
+    def comm_stats(self, reset: bool = True) -> dict:
+        """bytes reduced / gathered and the exposed communication time since the last call (synchronises the device: call it outside
+        the timed region).  `exposed_comm_ms` = device time between reaching a wait for outstanding collectives on the compute stream
+        and getting past it: what overlap did NOT hide."""
+        if self._exposed:
+            torch.cuda.synchronize()
+        out = {"bytes_reduced": int(self.bytes_reduced), "bytes_gathered": int(self.bytes_gathered),
+               "exposed_comm_ms": round(sum(a.elapsed_time(b) for a, b in self._exposed), 3), "waits": len(self._exposed)}
+        if reset:
+            self.bytes_reduced = self.bytes_gathered = 0
+            self._exposed = []
+        return out
 
     def step(self):
         """clip (global norm over ALL ranks' slices) + AdamW on the owned slices + all-gather of the weights"""
@@ -1002,13 +1035,21 @@ class DistributedOptimizer:
                 # in place (sendbuff == recvbuff + rank * sendcount), issued as soon as THIS bucket's slice is updated: RCCL's
                 # stream picks up behind the AdamW kernel just enqueued, so the gather of bucket k runs under the update of k+1
                 works.append(dist.all_gather_into_tensor(p[a:b], p[oa:ob], group=self.group, async_op=True))
+                self.bytes_gathered += (b - a) * 4
         if self.collective and gloo:
             for (a, b) in self.buckets:
                 n = (b - a) // self.world
                 dist.all_gather([p[a + r * n:a + (r + 1) * n] for r in range(self.world)], p[a + self.rank * n:a + (self.rank + 1) * n].clone(),
                                 group=self.group)
+        if works and p.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in works:
             w.wait()
+        if works and p.is_cuda:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._exposed.append((e0, e1))
         self.flat.bump()
         return float(total)
 
@@ -1392,6 +1433,12 @@ class MVLDMTrainer:
             key.append(tuple(k))
         return tuple(key)
 
+    def _prefetch_ok(self) -> bool:
+        if not self.opt.collective:
+            return True
+        import torch.distributed as dist
+        return dist.get_backend(self.opt.group) != "gloo"
+
     @staticmethod
     def _choices_key(choices):
         """the explicit draws a window was prepared with (index, second, relative_coin, unconditional, noise, timestep, encode_noise per
@@ -1451,10 +1498,10 @@ class MVLDMTrainer:
             self._run_overlapped(tp)
         else:
             tp.run()
-        if prefetch is not None and not self.opt.collective:
-            # the NEXT window's host part + VAE encode, on a side stream, under this window's backward.  Single-rank runs only: beside
-            # the bucket collectives it is unverified on RCCL (no multi-GPU box here) and pathological on the test backend (two gloo
-            # ranks sharing one GPU: 2.6 -> 57 s per optimizer step) -- with collectives the window encodes at its own call
+        if prefetch is not None and self._prefetch_ok():
+            # the NEXT window's host part + VAE encode, on a side stream, under this window's backward (and, on RCCL, beside its bucket
+            # reduce-scatters, which run on RCCL's own stream).  Not on the gloo test backend: two CPU-staged ranks sharing one GPU made
+            # it pathological (2.6 -> 57 s per optimizer step); there the window encodes at its own call.
             self._start_prefetch(*prefetch)
         losses = tp.loss * acc
         self.micro += acc
@@ -1471,6 +1518,7 @@ class MVLDMTrainer:
         cuts = bucket_cut_points(tp.grad_writes, self.opt.buckets, n_ops)
         cuts = [(k, par_safe_cut(tp.plan.ops, end)) for k, end in cuts]       # never inside a parallel group (plan_run_range refuses that)
         done = 0
+        self.opt.bucket_events = {}
         for k, end in cuts:
             if end > done:
                 tp.run(done, end)
@@ -1478,6 +1526,9 @@ class MVLDMTrainer:
             self.opt.reduce_bucket(k)
         if done < n_ops:
             tp.run(done, n_ops)
+        if torch.cuda.is_available():
+            self._bwd_done_event = torch.cuda.Event(enable_timing=True)      # (tests: every bucket but the last went out before this)
+            self._bwd_done_event.record()
 
 
 def gradient_drift_vs_f32(trainer: "MVLDMTrainer", batch, **choices) -> dict:

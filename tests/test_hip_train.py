@@ -470,6 +470,55 @@ def test_rccl_branch_on_a_one_rank_group_equals_the_plain_step(golden, monkeypat
         dist.destroy_process_group()
 
 
+def test_window_with_collectives_prefetch_and_repack_streams_on_a_one_rank_nccl_group(golden, monkeypatch):
+    """Everything the 8-GPU training step does that CAN be proven on one GPU: the accumulation WINDOW plan with
+    `collective=True` on a 1-rank `nccl` group -- bucket reduce-scatters on RCCL's stream under the backward pass -- together with the
+    encoder prefetch on its side stream and the weight re-pack on its side stream: three windows bit-identical (losses, gradient norm,
+    weights) to the plain single-stream step; every bucket's reduce except the last one's was ENQUEUED (event on the compute stream)
+    before the backward plan had finished (event timestamps); the communication accounting adds up."""
+    import socket
+    import torch.distributed as dist
+    from mv_ldm_amd.train import OptimizerCfg
+    monkeypatch.setenv("MVLDM_TRAIN_AUTOTUNE", "0")
+    g = golden("g9_training_step")
+    b0, b1 = g9_case(g, 0)[0], g9_case(g, 2)[0]
+    ch0, ch1 = hip_choices(g9_case(g, 0)[1]), hip_choices(g9_case(g, 2)[1])
+    seq = [([b0, b1], [ch0, ch1]), ([b1, b1], [ch1, ch1]), ([b0, b1], [ch0, ch1])]
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = []
+        for collective in (False, True):
+            monkeypatch.setenv("MVLDM_TRAIN_REPACK_AHEAD", "1" if collective else "0")
+            tr = build_trainer(g, torch.bfloat16, optimizer_cfg=OptimizerCfg(lr=1e-3), bucket_bytes=2 << 20,
+                               group=dist.group.WORLD if collective else None, collective=collective)
+            out = []
+            for i, (bts, chs) in enumerate(seq):
+                nxt = seq[i + 1] if collective and i + 1 < len(seq) else None
+                losses = tr.training_window(bts, chs, prefetch=nxt)
+                if collective:
+                    assert (tr.__dict__.get("_prefetched") is not None) == (nxt is not None)        # the side-stream encode really ran ahead
+                    torch.cuda.synchronize()
+                    evs, done = tr.opt.bucket_events, tr._bwd_done_event
+                    assert len(evs) == len(tr.opt.buckets) > 8
+                    early = sum(ev.elapsed_time(done) > 0.0 for ev in evs.values())
+                    assert early >= len(evs) - 1, (early, len(evs))                                 # enqueued while backward kernels were still to run
+                out.append(([float(x) for x in losses], float(tr.opt.norm[0])))
+            torch.cuda.synchronize()
+            if collective:
+                st = tr.opt.comm_stats()
+                assert st["bytes_reduced"] == 3 * tr.flat.numel * 4 and st["bytes_gathered"] == 3 * tr.flat.numel * 4 and st["exposed_comm_ms"] >= 0.0
+            got.append((out, tr.flat.flat.clone()))
+            del tr
+        assert got[0][0] == got[1][0], (got[0][0], got[1][0])
+        assert torch.equal(got[0][1], got[1][1]), float((got[0][1] - got[1][1]).abs().max())
+    finally:
+        dist.destroy_process_group()
+
+
 def test_full_width_f32_micro_batch_vs_oracle_autograd():
     """`DiffusionWrapper.training_step` (diffusion_wrapper.py:324-411) at the RELEASED widths: one micro-batch (1 scene, 1 context
     + 3 target views, 256x256, 1.07 B parameters) on the f32 HIP path against `oracle.train.training_step` + torch.autograd on
