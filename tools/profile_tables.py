@@ -1,8 +1,8 @@
-"""turn the rocprofv3 output of tools/r04_profiles.sh into the tables committed under profiles/:
-  r04_kernel_stats.csv      per kernel template: dispatches, mean / total duration of ONE eager UNet + DDIM pass at 64 scenes (trial-free)
-  r04_mfma_util.json        per kernel template: SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES), VALU-active fraction, mean duration
-  r04_b1_timeline.json      one scene, graph replay: kernels per DDIM step, busy time (sum of kernel durations) against the wall time of a step
-python3 tools/r04_profile_tables.py <rocprof output dir>"""
+"""turn the rocprofv3 output of tools/rNN_profiles.sh into the tables committed under profiles/:
+  rNN_kernel_stats.csv      per kernel template: dispatches, mean / total duration of ONE eager UNet + DDIM pass at 64 scenes (trial-free)
+  rNN_mfma_util.json        per kernel template: SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES), VALU-active fraction, mean duration
+  rNN_b1_timeline.json      one scene, graph replay: kernels per DDIM step, busy time (sum of kernel durations) against the wall time of a step
+python3 tools/profile_tables.py <rocprof output dir> [round, e.g. 05]"""
 import csv
 import glob
 import json
@@ -13,6 +13,7 @@ from collections import defaultdict
 
 csv.field_size_limit(1 << 30)
 O = sys.argv[1]
+RND = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("MVLDM_ROUND", "05")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -38,7 +39,7 @@ if rows:
     for n, s, e in rows:
         agg[n].append((e - s) / 1e3)
     tot = sum(sum(v) for v in agg.values())
-    with open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv"), "w", newline="") as f:
+    with open(os.path.join(ROOT, "profiles", f"r{RND}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "dispatches", "mean_us", "total_us", "percent"])
         for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
@@ -64,9 +65,9 @@ if pm:
             e["valu_active_frac"] = round(m.get("SQ_ACTIVE_INST_VALU", 0.0) / m["SQ_BUSY_CU_CYCLES"], 4)
         out[n] = e
     out = dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms"]))
-    json.dump({"note": "one eager UNet + DDIM pass at 64 scenes, bf16, plans recorded from profiles/r04_tune_cache.json (no tile trial in the "
+    json.dump({"note": "one eager UNet + DDIM pass at 64 scenes, bf16, plans recorded from the round's tune cache (no tile trial in the "
                        "traced process); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES), mean over the template's dispatches",
-               "kernels": out}, open(os.path.join(ROOT, "profiles", "r04_mfma_util.json"), "w"), indent=1)
+               "kernels": out}, open(os.path.join(ROOT, "profiles", f"r{RND}_mfma_util.json"), "w"), indent=1)
     print("pmc:", len(out), "templates")
 
 # ---- 3. one scene: busy vs wall per DDIM step (graph replay)
@@ -95,5 +96,5 @@ if rows:
             per[nme].append((e - s) / 1e3)
         res["by_template_last_step"] = {k: {"n": len(v), "total_us": round(sum(v), 1), "mean_us": round(sum(v) / len(v), 2)}
                                         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:25]}
-        json.dump(res, open(os.path.join(ROOT, "profiles", "r04_b1_timeline.json"), "w"), indent=1)
+        json.dump(res, open(os.path.join(ROOT, "profiles", f"r{RND}_b1_timeline.json"), "w"), indent=1)
         print("b1:", {k: v for k, v in res.items() if k != "by_template_last_step"})

@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/b64 -o p -- python3 b
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1 -o p -- python3 tools/step_trace.py 1 20 > $O/b1.log 2>&1
 # 3. MFMA / VALU busy per kernel (PMC pass on its own: no trace domains beside --kernel-trace)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $O/pmc -o p -- python3 bench.py --unet-pass-only > $O/pmc.log 2>&1
-python3 tools/r04_profile_tables.py $O
+python3 tools/profile_tables.py $O 04
 cmp -s /tmp/tune_cache_before.json profiles/r04_tune_cache.json && echo "tune cache unchanged: no problem was timed in the traced runs" | tee $O/trial_free.txt
 # keep the small summaries, drop the raw traces (gpurun_out/ is capped at 64 MiB)
 for d in b64 b1 pmc; do

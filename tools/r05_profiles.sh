@@ -1,0 +1,23 @@
+#!/bin/bash
+# round-5 evidence in one call on the GPU box:  bash tools/r05_profiles.sh
+#   0. the full default bench line (writes the round's tune cache, which makes every traced process below trial-free)
+#   1. rocprofv3 kernel trace + stats of one eager UNet + DDIM pass at 64 scenes (the population `roofline` is quoted on)
+#   2. 20 graph replays of the ONE-scene step under the tracer (tile 15 on) + the per-op table of that step
+#   3. MFMA / VALU busy per kernel (PMC pass of its own)
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp MVLDM_TUNE_CACHE=$PWD/gpurun_out/r05_tune_cache.json
+O=gpurun_out/r05prof; mkdir -p $O
+rm -f $MVLDM_TUNE_CACHE
+python3 bench.py > gpurun_out/r05_bench.json 2> $O/bench.err
+tail -c 600 gpurun_out/r05_bench.json; echo
+cp $MVLDM_TUNE_CACHE /tmp/tune_cache_before.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/b64 -o p -- python3 bench.py --unet-pass-only > $O/b64.log 2>&1
+MVLDM_OP_TABLE=$PWD/gpurun_out/r05_optable_b1.json rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1 -o p -- python3 tools/step_trace.py 1 20 > $O/b1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $O/pmc -o p -- python3 bench.py --unet-pass-only > $O/pmc.log 2>&1
+python3 tools/profile_tables.py $O 05
+cmp -s /tmp/tune_cache_before.json $MVLDM_TUNE_CACHE && echo "tune cache unchanged: no problem was timed in the traced runs" | tee $O/trial_free.txt
+for d in b64 b1 pmc; do
+  cp $O/$d/p_kernel_stats.csv $O/${d}_kernel_stats.csv 2>/dev/null
+  rm -rf $O/$d
+done
+cp profiles/r05_kernel_stats.csv profiles/r05_mfma_util.json profiles/r05_b1_timeline.json $O/ 2>/dev/null
