@@ -814,7 +814,7 @@ def main():
         targs.steps, targs.warmup, targs.op_table, targs.scenes = 4, 2, None, 64
         t = train_bench(targs, den, vae, dev, dtype, rank, world, dist, backend, barrier, n_params)
         out["training"] = {k: t[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "micro_batch_ms",
-                                              "micro_batch_tflops", "grad_norm", "roofline", "grad_rel_err") if k in t}
+                                              "micro_batch_tflops", "grad_norm", "roofline", "grad_rel_err", "randomised", "comm") if k in t}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.res // 8)
     if rank == 0:

@@ -257,14 +257,20 @@ static int gn_fused_plan(int hw, int c, int groups, int epc, int n_img, int& nth
     const int base = cpg / gcd(cpg, epc) * epc;       // lcm: whole groups and whole chunks
     if (base > c || c % base) return 0;
     int best = 0;
+#ifdef MVLDM_EXPERIMENTS
+    static const int x_span = getenv("MVLDM_GN_SPAN") ? atoi(getenv("MVLDM_GN_SPAN")) : 0, x_nthr = getenv("MVLDM_GN_NTHR") ? atoi(getenv("MVLDM_GN_NTHR")) : 1024;
+#else
+    constexpr int x_span = 0, x_nthr = 1024;
+#endif
     for (int m = 1; base * m <= c; ++m) {
         const int span = base * m;
         if (c % span || span / cpg > 64) continue;
+        if (x_span && x_span <= c && span != x_span) continue;
         const int cps = span / epc;
         const int l = cps / gcd(cps, 64) * 64;
         if (l > 1024) continue;
         // threads: whole waves, a whole number of rows per sweep, and no more than the slab has chunks (small images)
-        int n = 1024 / l * l;
+        int n = std::max(l, std::min(1024, x_nthr) / l * l);
         const long long chunks = (long long)hw * cps;
         while (n > l && (long long)(n - l) >= chunks) n -= l;
         const int k = (int)((chunks + n - 1) / n);

@@ -27,6 +27,7 @@ ap.add_argument("--only", default=None)
 ap.add_argument("--lib-suffix", default=None, help="EXPERIMENT library libmvldm_hip_exp<suffix>.so (tools/sk_probe.sh): results are wrong by design")
 ap.add_argument("--cfgs", default=None)
 ap.add_argument("--no-tiled", action="store_true")
+ap.add_argument("--set", default="low", choices=["low", "mid"], help="low: the 8x8 / 4x4-level launches (default); mid: the 32x32 / 16x16-level Linears (use --hot)")
 args = ap.parse_args()
 dt = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
 V = args.views
@@ -54,6 +55,20 @@ SHAPES = [
     ("temb linear_2 1280->1280", V, 1, 1280, 0, 1280, 1, 1, 0, "lin"),
     ("time_emb_proj[all] 1280->20480", V, 1, 1280, 0, 20480, 1, 1, 0, "lin"),
 ]
+MID = [
+    ("L1 linear 640->640", V * 256, 1, 640, 0, 640, 1, 1, 0, "lin"),
+    ("L1 qkv 640->1920", V * 256, 1, 640, 0, 1920, 1, 1, 0, "lin"),
+    ("L1 ff.out 2560->640", V * 256, 1, 2560, 0, 640, 1, 1, 0, "lin"),
+    ("L1 geglu 640->5120", V * 256, 1, 640, 0, 5120, 1, 1, 2, "lin"),
+    ("L0 linear 320->320", V * 1024, 1, 320, 0, 320, 1, 1, 0, "lin"),
+    ("L0 qkv 320->960", V * 1024, 1, 320, 0, 960, 1, 1, 0, "lin"),
+    ("L0 ff.out 1280->320", V * 1024, 1, 1280, 0, 320, 1, 1, 0, "lin"),
+    ("L0 geglu 320->2560", V * 1024, 1, 320, 0, 2560, 1, 1, 2, "lin"),
+    ("L1 shortcut 1x1 1920->640", V, 16, 1280, 640, 640, 1, 1, 0, "conv"),
+    ("L0 shortcut 1x1 960->320", V, 32, 640, 320, 320, 1, 1, 0, "conv"),
+]
+if args.set == "mid":
+    SHAPES = MID
 
 
 def timed(fn, n_iter):
@@ -123,7 +138,7 @@ for name, ni, h, c0, c1, co, k, stride, epi, kind in SHAPES:
     ref.replay(); torch.cuda.synchronize()
     ref_out = dst.float().clone()
     res = []
-    for tile in ((0,) if args.no_tiled else (0, 1, 2, 3, 4, 5)):
+    for tile in ((0,) if args.no_tiled else ((0, 1, 2, 3, 4, 5) if args.set == "low" else range(0, 15))):
         for sk in ((0,) if args.no_tiled else (0, 1, 2, 4, 8, 16, 32)):
             try:
                 plan = make_plan(tile, sk)
