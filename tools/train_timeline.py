@@ -64,6 +64,9 @@ if os.environ.get("MVLDM_TIMELINE_PER_MICRO") != "1":
         _, t = timed(lambda: tr._repack_ahead(tp)); add("weight re-pack (side stream, here waited for)", t)
     print({k: round(v / N, 2) for k, v in acc.items()}, "ms per optimizer step, phases serialised;", round(sum(acc.values()) / N, 2), "ms summed;",
           round(whole, 2), "ms per training_window() unserialised")
+    _, t1 = timed(lambda: [fn() for fn in tp.repack])
+    _, t2 = timed(lambda: tp._pack_batch.run() if tp._pack_batch is not None else None)
+    print(f"re-pack: {len(tp.repack)} fp32 refresh closures {t1:.2f} ms, {len(tp.pack_jobs)} pack jobs in one batch {t2:.2f} ms")
     sys.exit(0)
 for it in range(3):
     for micro in range(2):
