@@ -720,7 +720,7 @@ template <typename T> static int launch_attn_wide(const AttnParams& p, int n_seg
 // block (+3 %), per-view / SD self-attention -2...-6 %, the block-B-exponentials-between-block-A-MFMAs schedule 6.41 ms:
 // the kernel is bound by VALU issue (70 % VALU-active at 42 % MFMA-busy, 11 VALU instructions per MFMA at d = 40), which
 // neither sharing fragments nor re-ordering reduces.  Default: one block per wave.
-static const int kEnvAttnQB = getenv("MVLDM_ATTN_QB") ? atoi(getenv("MVLDM_ATTN_QB")) : 1;
+static const int kEnvAttnQB = knob_int("MVLDM_ATTN_QB", 1);
 
 template <typename T, int DP, bool ONES, int QB> static int launch_attn_k(AttnParams p, int n_seg, int max_q_len, hipStream_t s) {
     constexpr bool F32 = std::is_same<T, float>::value;
@@ -771,7 +771,7 @@ int attention_run(const void* q, const void* k, const void* v, void* out, int ld
         using T = decltype(t);
         if (head_dim > 160) {
             if constexpr (sizeof(T) == 2) {       // the VAE's single 512-wide head: d split over the four waves, MFMA (MVLDM_ATTN_WIDE_VALU=1: the VALU form)
-                static const bool valu = getenv("MVLDM_ATTN_WIDE_VALU") && atoi(getenv("MVLDM_ATTN_WIDE_VALU")) != 0;
+                static const bool valu = knob_int("MVLDM_ATTN_WIDE_VALU", 0) != 0;
                 if (head_dim == 512 && !valu && !p.lse) return launch_attn_dsplit<T, 128>(p, n_seg, max_q_len, s);
             }
             return launch_attn_wide<T>(p, n_seg, max_q_len, s);

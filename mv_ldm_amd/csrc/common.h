@@ -94,8 +94,19 @@ template <typename T> __device__ __forceinline__ void store_chunk(T* p, const Ch
 }
 // host: should a kernel that writes `bytes` of output use streaming stores?  Outputs of half the 256 MB Infinity Cache or more;
 // MVLDM_STREAM_STORES=0 / 1 forces it (A/B knob).
+// A/B and tuning knobs of decisions already made exist in EXPERIMENT builds only (-DMVLDM_EXPERIMENTS: tools/*_probe.sh,
+// MVLDM_EXPERIMENTS=1 python -m mv_ldm_amd._build): the product library's kernels and dispatch read no environment variable.
+static inline int knob_int(const char* name, int dflt) {
+#ifdef MVLDM_EXPERIMENTS
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 static inline int stream_stores(size_t bytes) {
-    static const int force = getenv("MVLDM_STREAM_STORES") ? atoi(getenv("MVLDM_STREAM_STORES")) : -1;
+    static const int force = knob_int("MVLDM_STREAM_STORES", -1);
     return force >= 0 ? force : (bytes >= ((size_t)128 << 20));
 }
 

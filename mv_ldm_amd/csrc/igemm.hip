@@ -1444,10 +1444,7 @@ static inline bool deep_tile(int tile) { return tile == 18; }
 
 // tuning knobs (read once): MVLDM_IGEMM_STAGES (0 = heuristic), MVLDM_IGEMM_TARGET (split-K workgroup
 // target), MVLDM_IGEMM_SYNC=1 (force the register-prefetch main loop for 16-bit types: A/B testing)
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+static int env_int(const char* name, int dflt) { return knob_int(name, dflt); }      // (experiment builds only: common.h)
 static const int kEnvTarget = env_int("MVLDM_IGEMM_TARGET", 0);
 static const int kEnvSync = env_int("MVLDM_IGEMM_SYNC", 0);
 static const int kEnvPx = env_int("MVLDM_IGEMM_PX", 0);
@@ -1782,7 +1779,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
         // minimises the partition's fabric traffic A_x * ceil(sub_n / gn) + W_x * ceil(sub_m / gm) with gm * gn = 32.
         // MVLDM_IGEMM_GROUP=0 keeps the one-row / one-column order (A/B knob), "gm" forces the row count.
         p.grp_m = p.grp_n = 1;
-        static const int kGroup = getenv("MVLDM_IGEMM_GROUP") ? atoi(getenv("MVLDM_IGEMM_GROUP")) : -1;
+        static const int kGroup = knob_int("MVLDM_IGEMM_GROUP", -1);
         if (kGroup != 0 && tile >= 7 && tile <= 10 && p.sub_m * p.sub_n > 32) {
             const double ax = a_bytes / p.px, wx = w_bytes / (8 / p.px);
             double bestc = 1e300;

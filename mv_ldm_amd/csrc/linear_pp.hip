@@ -42,9 +42,9 @@ struct LinPPParams {
 
 // MVLDM_LPP_FAKE (roofline experiments of tools/fake_probe.sh only, compiled in only with -DMVLDM_EXPERIMENTS; results are
 // WRONG): 1 = activation pieces read as zeros without memory traffic, 2 = same for the weight, 4 = no stores
-static const int kLppCpt = getenv("MVLDM_LPP_CPT") ? atoi(getenv("MVLDM_LPP_CPT")) : 0;   // tuning: force the unit length
+static const int kLppCpt = knob_int("MVLDM_LPP_CPT", 0);   // tuning: force the unit length
 #ifdef MVLDM_EXPERIMENTS
-static const int kLppFake = getenv("MVLDM_LPP_FAKE") ? atoi(getenv("MVLDM_LPP_FAKE")) : 0;
+static const int kLppFake = knob_int("MVLDM_LPP_FAKE", 0);
 #else
 static constexpr int kLppFake = 0;
 #endif

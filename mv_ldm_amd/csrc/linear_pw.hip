@@ -47,7 +47,7 @@ struct LinPWParams {
 };
 
 #ifdef MVLDM_EXPERIMENTS
-static const int kPwFake = getenv("MVLDM_PW_FAKE") ? atoi(getenv("MVLDM_PW_FAKE")) : 0;   // 1: no A traffic, 2: no W traffic, 4: no stores
+static const int kPwFake = knob_int("MVLDM_PW_FAKE", 0);   // 1: no A traffic, 2: no W traffic, 4: no stores
 #else
 static constexpr int kPwFake = 0;
 #endif
@@ -499,7 +499,7 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     // 256 x 320 when the packed width is a multiple of 320 (every channel count of this UNet), else 256 x 256; GEGLU pairs need an even
     // number of column blocks per wave
     const bool geglu = d.epilogue == MVLDM_EPI_GEGLU;
-    static const int kForceTn = getenv("MVLDM_PW_TN") ? atoi(getenv("MVLDM_PW_TN")) : 0;
+    static const int kForceTn = knob_int("MVLDM_PW_TN", 0);
     int tn_blocks = (!geglu && d.n_pad % 320 == 0) ? 5 : 4;
     if (kForceTn == 4 || (kForceTn == 5 && !geglu)) tn_blocks = kForceTn;
     const int bn = 64 * tn_blocks;
@@ -510,7 +510,7 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     p.res_bytes = d.residual ? (unsigned)((double)p.M * p.n_dst * 2.0) : 0u;
     p.dst_bytes = (unsigned)((double)p.M * p.dst_ld * 2.0);
     // write-back stores unless forced (header): MVLDM_STREAM_STORES=1 is the A/B knob
-    static const int kNt = getenv("MVLDM_STREAM_STORES") ? atoi(getenv("MVLDM_STREAM_STORES")) : 0;
+    static const int kNt = knob_int("MVLDM_STREAM_STORES", 0);
     p.nt_store = kNt == 1;
     if (kPwFake & 1) p.a_bytes = p.a1_bytes = 0;
     if (kPwFake & 2) p.w_bytes = 0;
@@ -541,7 +541,7 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
             const double cost = gm * a_t + gn * w_t;
             if (cost < best_cost) { best_cost = cost; p.gm = gm; p.gn = gn; }
         }
-    static const int kForceGm = getenv("MVLDM_PW_GM") ? atoi(getenv("MVLDM_PW_GM")) : 0;   // tuning: force the block shape
+    static const int kForceGm = knob_int("MVLDM_PW_GM", 0);   // tuning: force the block shape
     if (kForceGm > 0) { p.gm = std::min(std::min(kForceGm, cu_x), p.m_per); p.gn = std::max(1, std::min(cu_x / p.gm, p.tiles_n)); }
     p.nbn = (p.tiles_n + p.gn - 1) / p.gn;
     const int wpx = p.gm * p.gn;

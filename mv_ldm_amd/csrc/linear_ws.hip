@@ -34,7 +34,7 @@ struct LinWSParams {
 };
 
 #ifdef MVLDM_EXPERIMENTS
-static const int kWsFake = getenv("MVLDM_WS_FAKE") ? atoi(getenv("MVLDM_WS_FAKE")) : 0;   // 1: no A traffic, 4: no stores
+static const int kWsFake = knob_int("MVLDM_WS_FAKE", 0);   // 1: no A traffic, 4: no stores
 #else
 static constexpr int kWsFake = 0;
 #endif
@@ -341,7 +341,7 @@ int linear_ws_run(const mvldm_igemm_desc& d, hipStream_t s) {
     p.bias_bytes = d.bias ? (unsigned)d.n_out * 4u : 0u;
     p.res_bytes = d.residual ? (unsigned)((double)p.M * p.n_dst * 2.0) : 0u;
     p.dst_bytes = (unsigned)((double)p.M * p.dst_ld * 2.0);
-    static const int kNt = getenv("MVLDM_STREAM_STORES") ? atoi(getenv("MVLDM_STREAM_STORES")) : 0;
+    static const int kNt = knob_int("MVLDM_STREAM_STORES", 0);
     p.nt_store = kNt == 1;
     if (kWsFake & 1) p.a_bytes = 0;
     if (kWsFake & 4) p.dst_bytes = 0;

@@ -250,18 +250,14 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const T* __restrict__ x0
 // scene (9 images) the widest one left 36 workgroups of 960 threads on a 256-CU chip, 11 serial chunks each (16.7 us per launch,
 // 61 launches = 14 % of a DDIM step).  (MVLDM_GN_WIDE=1: always the widest, the round-2 rule -- A/B knob.)
 static int gn_fused_plan(int hw, int c, int groups, int epc, int n_img, int& nthr, int& kt) {
-    static const int force_wide = getenv("MVLDM_GN_WIDE") ? atoi(getenv("MVLDM_GN_WIDE")) : 0;
+    static const int force_wide = knob_int("MVLDM_GN_WIDE", 0);
     const int cpg = c / groups;
     if (!((cpg >= epc && true) || (epc % cpg == 0 && epc / cpg == 2))) return 0;
     auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
     const int base = cpg / gcd(cpg, epc) * epc;       // lcm: whole groups and whole chunks
     if (base > c || c % base) return 0;
     int best = 0;
-#ifdef MVLDM_EXPERIMENTS
-    static const int x_span = getenv("MVLDM_GN_SPAN") ? atoi(getenv("MVLDM_GN_SPAN")) : 0, x_nthr = getenv("MVLDM_GN_NTHR") ? atoi(getenv("MVLDM_GN_NTHR")) : 1024;
-#else
-    constexpr int x_span = 0, x_nthr = 1024;
-#endif
+    static const int x_span = knob_int("MVLDM_GN_SPAN", 0), x_nthr = knob_int("MVLDM_GN_NTHR", 1024);      // profiles/r05_gn_sweep.txt
     for (int m = 1; base * m <= c; ++m) {
         const int span = base * m;
         if (c % span || span / cpg > 64) continue;
@@ -413,7 +409,7 @@ int groupnorm_run(const void* x, const void* x1, void* y, const float* gamma, co
     const int epc = dtype == MVLDM_F32 ? 4 : 8;
     MVLDM_REQUIRE(c0 % epc == 0 && c1 % epc == 0, "groupnorm: channels (%d,%d) must be multiples of %d", c0, c1, epc);
     if (n_img == 0 || hw == 0) return MVLDM_OK;
-    static const int no_fused = getenv("MVLDM_GN_TWOPASS") ? atoi(getenv("MVLDM_GN_TWOPASS")) : 0;   // A/B knob
+    static const int no_fused = knob_int("MVLDM_GN_TWOPASS", 0);
     int f_nthr = 0, f_kt = 0;
     const int f_span = no_fused ? 0 : gn_fused_plan(hw, c, groups, epc, n_img, f_nthr, f_kt);
     if (f_span) {
@@ -492,7 +488,7 @@ int layernorm_run(const void* x, void* y, const float* gamma, const float* beta,
 
 extern "C" int mvldm_groupnorm_passes(int n_img, int hw, int c, int groups, int dtype) {
     if (n_img <= 0 || hw <= 0 || groups <= 0 || c <= 0 || c % groups) return 3;
-    static const int no_fused = getenv("MVLDM_GN_TWOPASS") ? atoi(getenv("MVLDM_GN_TWOPASS")) : 0;
+    static const int no_fused = mvldm::knob_int("MVLDM_GN_TWOPASS", 0);
     int nthr = 0, kt = 0;
     return (!no_fused && mvldm::gn_fused_plan(hw, c, groups, dtype == MVLDM_F32 ? 4 : 8, n_img, nthr, kt)) ? 2 : 3;
 }

@@ -210,7 +210,7 @@ extern "C" int mvldm_plan_num_ops(const mvldm_plan* p) { return p ? (int)p->ops.
 extern "C" int mvldm_plan_run_range(mvldm_plan* p, int first, int last, mvldm_stream_t stream) {
     MVLDM_REQUIRE(p && first >= 0 && last <= (int)p->ops.size() && first <= last, "plan_run_range: bad range");
     hipStream_t s = (hipStream_t)stream, cur = s;
-    static const bool serial = getenv("MVLDM_PLAN_SERIAL") && atoi(getenv("MVLDM_PLAN_SERIAL"));      // A/B knob: ignore the lane markers
+    static const bool serial = knob_int("MVLDM_PLAN_SERIAL", 0) != 0;      // A/B knob: ignore the lane markers
     bool in_group = false;
     int lane = 0;
     if (!serial) {

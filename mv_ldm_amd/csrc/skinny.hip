@@ -48,7 +48,7 @@ struct SkParams {
 };
 
 #ifdef MVLDM_EXPERIMENTS
-static const int kSkFake = getenv("MVLDM_SK_FAKE") ? atoi(getenv("MVLDM_SK_FAKE")) : 0;   // 1 no W traffic, 2 no A traffic, 4 no stages, 8 empty kernel, 16 no fold / epilogue
+static const int kSkFake = knob_int("MVLDM_SK_FAKE", 0);   // 1 no W traffic, 2 no A traffic, 4 no stages, 8 empty kernel, 16 no fold / epilogue
 #else
 static constexpr int kSkFake = 0;
 #endif

@@ -468,7 +468,7 @@ int adamw_run(float* p, const float* g, float* m, float* v, size_t n, float lr, 
     MVLDM_REQUIRE(p && g && m && v && step >= 1, "adamw: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const bool vec = n % 4 == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
-    static const bool nt = !(getenv("MVLDM_ADAMW_NT") && atoi(getenv("MVLDM_ADAMW_NT")) == 0);
+    static const bool nt = knob_int("MVLDM_ADAMW_NT", 1) != 0;
     if (vec && nt)
         hipLaunchKernelGGL(adamw_kernel4<true>, dim3(grid_for(n / 4, 2048)), dim3(256), 0, s, reinterpret_cast<f32x4*>(p), reinterpret_cast<const f32x4*>(g),
                            reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), n / 4, lr, beta1, beta2, eps, weight_decay, (float)(lr / bc1),

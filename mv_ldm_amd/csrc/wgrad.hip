@@ -59,7 +59,7 @@ __device__ __forceinline__ bool wg_map(const WgradParams& p, int& tile, int& spl
     tile = i * cnt + rank;
     return tile < p.n_tiles;
 }
-static const int kWgXcd = getenv("MVLDM_WGRAD_XCD") ? atoi(getenv("MVLDM_WGRAD_XCD")) : 0;
+static const int kWgXcd = knob_int("MVLDM_WGRAD_XCD", 0);
 static inline int wg_grid(int tiles, int splits) {
     if (!kWgXcd) return tiles * splits;
     return splits >= 8 ? 8 * ((splits + 7) / 8) * tiles : 8 * ((tiles + (8 / splits) - 1) / (8 / splits));
@@ -444,7 +444,7 @@ int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits, int tcode
     p.kdim = p.taps * p.ctot;
     const int tiles = p.tiles_n * p.taps * p.tiles_c;
     const int blocks = cdiv_(p.M, WG_BP);
-    static const int kTarget = getenv("MVLDM_WGRAD_TARGET") ? atoi(getenv("MVLDM_WGRAD_TARGET")) : 512;   // workgroups aimed at (512 / 1024 / 2048 / 4096: 303 / 300 / 300 / 292 training views/s)
+    static const int kTarget = knob_int("MVLDM_WGRAD_TARGET", 512);   // workgroups aimed at (512 / 1024 / 2048 / 4096: 303 / 300 / 300 / 292 training views/s)
     // (bits 10-12 of the caller's `accumulate` -- the host's per-problem choice, plan.autotune_wgrad -- name the target: 64 << code)
     const int target = tcode ? (64 << tcode) : kTarget;
     splits = std::max(1, std::min(cdiv_(target, tiles), std::max(1, blocks / 4)));
@@ -461,7 +461,7 @@ int wgrad_plan(const mvldm_wgrad_desc& d, WgradParams& p, int& splits, int tcode
 // [n][tap * ctot + c] of the only split IS the PyTorch layout [n_out][c_in] -- the kernel writes the gradient itself, no slab, no reduce
 // launch (the big 1280-wide FF / QKV projections: 52 MB slabs that were written, re-read and written again).  MVLDM_WGRAD_DIRECT=0: A/B knob.
 static inline bool wgrad_direct(const mvldm_wgrad_desc& d, const WgradParams& p, int splits) {
-    static const int on = getenv("MVLDM_WGRAD_DIRECT") ? atoi(getenv("MVLDM_WGRAD_DIRECT")) : 1;
+    static const int on = knob_int("MVLDM_WGRAD_DIRECT", 1);
     return on && splits == 1 && p.taps == 1 && d.c_in == p.ctot && (d.accumulate & 1) == 0;
 }
 
@@ -496,9 +496,9 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s, int tcode = 
     q.lw = d.ksize == 3 ? ilog2_exact(d.w_out) : 0;
     q.lh = d.ksize == 3 ? ilog2_exact(d.h_out) : 0;
     // one workgroup per CU: whole rounds of 256, at least 4 pixel steps per split
-    static const int kBp = getenv("MVLDM_WGRAD_WIDE_BP") ? atoi(getenv("MVLDM_WGRAD_WIDE_BP")) : 64;      // 64: 2-slot ring (default), 32: 4-slot (measured 18 % slower)
+    static const int kBp = knob_int("MVLDM_WGRAD_WIDE_BP", 64);      // 64: 2-slot ring (default), 32: 4-slot (measured 18 % slower)
     const int tiles = p.tiles_n * p.taps * p.tiles_c, blocks = cdiv_(p.M, 64);
-    static const int kTarget = getenv("MVLDM_WGRAD_WIDE_TARGET") ? atoi(getenv("MVLDM_WGRAD_WIDE_TARGET")) : 256;      // one round of workgroups: half the slab traffic of two (512: 2324 us over tools/wgrad_bench.py, 256: 2190)
+    static const int kTarget = knob_int("MVLDM_WGRAD_WIDE_TARGET", 256);      // one round of workgroups: half the slab traffic of two (512: 2324 us over tools/wgrad_bench.py, 256: 2190)
     const int target = tcode ? (64 << tcode) : kTarget;
     splits = std::max(1, std::min(target / std::max(tiles, 1), std::max(1, blocks / 4)));
     const size_t slab = (size_t)d.n_out * p.kdim * sizeof(float);
@@ -548,7 +548,7 @@ static int wgrad_run_wide(const mvldm_wgrad_desc& d, hipStream_t s, int tcode = 
 // the wide form wins on the 3x3 convs with long pixel ranges (level 0: 1.7x) and with short ones (<= 4096 pixels, many tiles),
 // and on Linears with K >= 1024 and few output columns; the 16x16 level and the wide-N Linears stay with the small tile.
 static bool wgrad_pick_wide(const mvldm_wgrad_desc& d) {
-    static const int force = getenv("MVLDM_WGRAD_WIDE") ? atoi(getenv("MVLDM_WGRAD_WIDE")) : -1;      // A/B knob: 0 never, 1 wherever it applies
+    static const int force = knob_int("MVLDM_WGRAD_WIDE", -1);      // A/B knob: 0 never, 1 wherever it applies
     const int form = (d.accumulate >> 8) & 3;
     if (!wgrad_wide_ok(d)) return false;
     if (form) return form == 2;

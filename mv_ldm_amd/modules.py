@@ -451,8 +451,7 @@ class Upsample2D(nn.Module):
 
     def emit(self, b: Builder, x):
         c = x.shape[-1]
-        if (b.dtype != torch.float32 and c % ops.block_k(b.dtype) == 0 and self.conv.out_channels % 8 == 0
-                and os.environ.get("MVLDM_UPSAMPLE_GATHER", "0") != "1"):     # (A/B knob: 1 = the 9-tap gather form)
+        if b.dtype != torch.float32 and c % ops.block_k(b.dtype) == 0 and self.conv.out_channels % 8 == 0:
             # nearest x2 + 3x3 = four 2x2 convs on the low-resolution image (4/9 of the multiply-adds)
             pws = self.conv._cache(("wphase", b.dtype), [self.conv.weight],
                                    lambda: [ops.pack_weight(w, b.dtype) for w in ops.upsample_phase_weights(self.conv.weight)])

@@ -160,9 +160,9 @@ class PackBatch:
         self.total_blocks = b0
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
         self.table = raw.to(device)
-        # workgroup -> job (MVLDM_PACK_BLOCK_TABLE=0: the kernel searches the job list instead; A/B)
+        # workgroup -> job table (without it the kernel searches the job list: measured slower, HISTORY 3.2)
         self.block_job = None
-        if os.environ.get("MVLDM_PACK_BLOCK_TABLE", "1") != "0" and jobs:
+        if jobs:
             self.block_job = torch.repeat_interleave(torch.arange(len(jobs), dtype=torch.int32), torch.tensor([j.blocks for j in jobs])).to(device)
             assert self.block_job.numel() == b0
 
