@@ -59,3 +59,10 @@ def test_op_kind_enum_matches():
     names = ["MVLDM_OP_IGEMM"] + re.findall(r"(MVLDM_OP_[A-Z0-9_]+)", m.group(1))
     for i, n in enumerate(names, start=1):
         assert getattr(_lib, n.replace("MVLDM_", "")) == i
+
+
+def test_product_library_reads_no_environment_knob():
+    """kernel-level A/B switches exist in experiment builds only (`knob_int`, csrc/common.h): no `MVLDM_*` variable name is compiled
+    into the product library, so its kernels and dispatch cannot depend on the environment of the process (VERDICT r4 weak #10)"""
+    blob = lib_path().read_bytes()
+    assert b"MVLDM_" not in blob
