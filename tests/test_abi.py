@@ -64,5 +64,5 @@ def test_op_kind_enum_matches():
 def test_product_library_reads_no_environment_knob():
     """kernel-level A/B switches exist in experiment builds only (`knob_int`, csrc/common.h): no `MVLDM_*` variable name is compiled
     into the product library, so its kernels and dispatch cannot depend on the environment of the process (VERDICT r4 weak #10)"""
-    blob = lib_path().read_bytes()
+    blob = SO.read_bytes()
     assert b"MVLDM_" not in blob
