@@ -61,8 +61,9 @@ def test_op_kind_enum_matches():
         assert getattr(_lib, n.replace("MVLDM_", "")) == i
 
 
-def test_product_library_reads_no_environment_knob():
+def test_product_library_reads_no_environment_knob(lib):
     """kernel-level A/B switches exist in experiment builds only (`knob_int`, csrc/common.h): no `MVLDM_*` variable name is compiled
     into the product library, so its kernels and dispatch cannot depend on the environment of the process (VERDICT r4 weak #10)"""
-    blob = SO.read_bytes()
+    from mv_ldm_amd import _lib
+    blob = Path(_lib.LIB_PATH).read_bytes()
     assert b"MVLDM_" not in blob
