@@ -1128,6 +1128,151 @@ __global__ __launch_bounds__(512) void igemm_halo_kernel(const IgemmParams p, in
     igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
 }
 
+// ---- tile 17 (round 5): the pixel halo under a 256 x 320 tile, for maps up to 24 pixels wide ------------------------------------
+// Tile 10 (256 x 320, the headline's 3x3 convs) idles its matrix pipes 31 % of the time with both waves of a SIMD parked on the next
+// K-tile's round trip: 72 KB per CU per step through the 2-slot ring.  With the halo resident (one fill of 256 + 2 (W + 1) pixel
+// rows per channel block serves the 9 taps) a step moves 40 KB of weights + 1/9 of the 37 KB halo = 44 KB.  LDS: two halo buffers +
+// a 2-slot weight ring = 2 x 37 + 2 x 40 KB at W = 16 (156 KB); a 32-wide map needs 164 KB -- level 0 stays on tile 10.
+// 8 waves of 64 x 160 like tile 10 (10 accumulator blocks: fragments are fetched right before use, the two waves of a SIMD cover each
+// other's LDS latency); per step a wave issues 5 weight pieces + 1 halo piece behind the barrier, and the counted wait in front of
+// the next barrier (vmcnt(1): only the halo piece may still be in flight) is for the weights issued one step earlier.
+template <typename T>
+__global__ __launch_bounds__(512) void igemm_halow_kernel(const IgemmParams p, int halo_rows) {
+    using M_ = Mma<T>;
+    constexpr int BM = 256, BN = 320, WM = 4, WN = 2, NW = 8, TM = 2, TN = 5, B_IT = 5, KA = 6, EPC = 8;
+    constexpr int W_BYTES = BN * 128;
+    static_assert(64 / M_::KI == 4, "four k-sub-steps per K-tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int a_bytes = halo_rows * 128;
+    char* const wring = smem + 2 * a_bytes;
+    char* const zrow = wring + 2 * W_BYTES;
+    char* const dummy = zrow + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    int split, tm, tn;
+    if (!map_block(p, split, tm, tn)) return;
+    const int cb1 = p.k_tiles / 9;
+    const int lead = p.w_in + 1;
+    const int m0 = tm * BM;
+    const int np = halo_rows / 8;                       // 1 KiB pieces of a halo tile
+    const int slot = lane & 7, rsub = lane >> 3;
+    const int m_tot = p.n_img * p.h_in * p.w_in;
+
+    if (tid < 8) *reinterpret_cast<u32x4*>(zrow + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+
+    unsigned off0[KA];
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        const int q = wave + NW * k;
+        const int hr = q * 8 + rsub;
+        const int pm = m0 - lead + hr;
+        const bool ok = q < np && pm >= 0 && pm < m_tot;
+        const unsigned chunk = (unsigned)((slot ^ ((hr >> 1) & 7)) * EPC);
+        off0[k] = ok ? ((unsigned)pm * (unsigned)p.c0 + chunk) * 2u : kOob;
+    }
+    unsigned vb[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int row = (wave + NW * it) * 8 + rsub;
+        const int n = tn * BN + row;
+        const unsigned chunk = (unsigned)((slot ^ ((row >> 1) & 7)) * EPC);
+        vb[it] = n < p.n_pad ? ((unsigned)n * (unsigned)p.k_pad + chunk) * 2u : kOob;
+    }
+    unsigned mask[TM];
+    int rloc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        rloc[i] = wm * (BM / WM) + i * 32 + l31;
+        const int m = m0 + rloc[i];
+        unsigned msk = 0;
+        if (m < p.M) {
+            const int rem = m % p.hw_out;
+            const int y = rem / p.w_out, x = rem - y * p.w_out;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                msk |= ((unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) ? (1u << t) : 0u;
+            }
+        }
+        mask[i] = msk;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define MVLDM_HW_A(k_, cb_)                                                                                            \
+    {                                                                                                                  \
+        const int q_ = wave + NW * (k_);                                                                               \
+        const bool real_ = (cb_) < cb1 && q_ < np;                                                                     \
+        halo_issue_a<false>(p, real_ ? smem + ((cb_) & 1) * a_bytes + q_ * 1024 : dummy, real_ ? off0[k_] : kOob, kOob, \
+                            (cb_) < cb1 ? (cb_) : 0);                                                                  \
+    }
+#define MVLDM_HW_W(kt_, ws_)                                                                                           \
+    {                                                                                                                  \
+        const bool real_ = (kt_) < cb1 * 9;                                                                            \
+        _Pragma("unroll") for (int it = 0; it < B_IT; ++it)                                                            \
+            halo_issue_w(p, wring + (ws_) * W_BYTES + (wave + NW * it) * 1024, real_ ? vb[it] : kOob, real_ ? (kt_) * 128 : 0); \
+    }
+
+    // prologue: the whole halo of block 0, W tiles 0 and 1
+#pragma unroll
+    for (int k = 0; k < KA; ++k) MVLDM_HW_A(k, 0)
+    MVLDM_HW_W(0, 0)
+    MVLDM_HW_W(1, 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int kt = 0;
+    for (int cb = 0; cb < cb1; ++cb) {
+        const char* as = smem + (cb & 1) * a_bytes;
+        // (the per-tap row offsets are loop-invariant: hipcc hoists all 9 x TM of them and spills 46 registers to scratch, whose reloads
+        //  count in vmcnt like the DMA pieces.  Opaque per-iteration values keep the two selects per tap inside the loop.)
+        asm volatile("" : "+v"(mask[0]), "+v"(mask[1]), "+v"(rloc[0]), "+v"(rloc[1]));
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++kt) {
+            const int ws = kt & 1;
+            const int disp = lead + (t / 3 - 1) * p.w_in + (t % 3 - 1);      // lane-uniform row displacement of the tap
+            const char* abase[TM];
+            int arow[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bool ok = (mask[i] >> t) & 1u;
+                abase[i] = ok ? as : zrow;
+                arow[i] = ok ? rloc[i] + disp : 0;
+            }
+            const char* bt = wring + ws * W_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                BlFrags<T, TM, TN> f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) f.a[i] = M_::load(abase[i], arow[i], kk, hi);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) f.b[j] = M_::load(bt, wn * (BN / WN) + j * 32 + l31, kk, hi);
+                bl_mma<T, TM, TN>(f, acc);
+            }
+            // W tile kt+1 has landed (behind it only the halo piece issued with it may still be in flight); every wave is done with
+            // W slot `ws` -- and, after tap 8, with this block's halo buffer
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            MVLDM_HW_W(kt + 2, ws)
+            if (t < KA) { MVLDM_HW_A(t, cb + 1) }
+            else { MVLDM_HW_A(0, cb1) }                                       // (keeps the per-step load count uniform)
+        }
+    }
+#undef MVLDM_HW_A
+#undef MVLDM_HW_W
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    igemm_epilogue_staged<T, BM, BN, WM, WN>(p, acc, tm, tn, split, wm, wn, wave, lane, smem);
+}
+
 // split-K: sum the fp32 partial slabs and run the same epilogue (deterministic, no atomics)
 template <typename T> __global__ __launch_bounds__(256) void igemm_splitk_reduce(const IgemmParams p) {
     const bool geglu = p.epilogue == MVLDM_EPI_GEGLU;
@@ -1436,7 +1581,8 @@ static const TileCfg kTiles[] = {{0, 0, 0}, {128, 128, 256}, {128, 64, 256}, {64
                                                      // multiple of 320 (no N padding); 142 flop per L2->LDS byte
                                  {256, 128, 512},    // tile 11: 256x128 with the LDS-resident pixel halo (3x3 stride-1 convs)
                                  {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},      // 12 - 14: linear_pp / linear_pw / linear_ws (own files); 15 unused
-                                 {0, 0, 0}, {0, 0, 0},     // 16 / 17: deep-ring forms of tiles 2 / 4, measured slower, not built
+                                 {0, 0, 0},          // 16: unused (deep-ring form of tile 2, measured slower, not built)
+                                 {256, 320, 512},    // tile 17: 256x320 with the LDS-resident pixel halo (3x3 stride-1 convs on maps <= 24 wide)
                                  // deep-ring tile for launches of a few hundred rows (weight-bound: levels 2 - 4 at a few scenes):
                                  {192, 128, 512}};   // tile 18: 8 waves of 96x32, 4 slots (160 KB): <= 192 rows read every weight byte once
 constexpr int kNumTiles = 11;
@@ -1554,8 +1700,17 @@ template <typename T> static int launch_halo(const IgemmParams& p, hipStream_t s
     return check_launch();
 }
 
+static inline int halow_smem(int w_in) { return 2 * halo_rows_for(w_in) * 128 + 2 * 320 * 128 + 128 + 1024; }
+template <typename T> static int launch_halow(const IgemmParams& p, hipStream_t s) {
+    static std::atomic<uint64_t> done{0};
+    if (int rc0 = ensure_dyn_smem(reinterpret_cast<const void*>(igemm_halow_kernel<T>), 160 * 1024, done)) return rc0;
+    hipLaunchKernelGGL((igemm_halow_kernel<T>), dim3(8 * p.sub_m * p.sub_n), dim3(512), halow_smem(p.w_in), s, p, halo_rows_for(p.w_in));
+    return check_launch();
+}
+
 template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStream_t s) {
     switch (tile) {
+#ifndef MVLDM_TILE_SUBSET      // (resource-usage / quick-compile experiments build the tiles under study only; never the library)
         case 1: return launch_tile<T, 128, 128, 2, 2>(p, s);
         case 2: return launch_tile<T, 128, 64, 4, 1>(p, s);
         case 3: return launch_tile<T, 64, 128, 2, 2>(p, s);
@@ -1591,8 +1746,14 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
                 if (p.use_bl) return launch_halo<T>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 11 needs the 16-bit block-major path");
+#endif
+        case 17:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_halow<T>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 17 needs the 16-bit block-major path");
         case 18:
-            // (tiles 16 / 17 -- 128x64 with 5 slots, 64x64 with 6 -- were built and measured SLOWER than their 2-slot forms on every
+            // (deep-ring forms of tiles 2 / 4 -- 128x64 with 5 slots, 64x64 with 6 -- were built and measured SLOWER than their 2-slot forms on every
             //  one-scene shape (tools/skinny_probe.py: 25.2 / 30.2 us against 22.0 / 21.8 on the 4x4-level conv): several 2-slot
             //  workgroups per CU already overlap each other's round trips; not instantiated)
             // (GEGLU pairs a value block with the gate block 32 columns on INSIDE a wave's tile: a 32-column wave tile cannot -- refused,
@@ -1693,7 +1854,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
     t_force_sync = (d.tile >> 12) & 1;
     const int force_px = (d.tile >> 8) & 15;
     int splitk = d.splitk;
-    MVLDM_REQUIRE(((tile >= 0 && tile <= kNumTiles) || deep_tile(tile)) && splitk >= 0, "igemm: tile/splitk");
+    MVLDM_REQUIRE(((tile >= 0 && tile <= kNumTiles) || tile == 17 || deep_tile(tile)) && splitk >= 0, "igemm: tile/splitk");
     choose_config(d, p.M, p.k_tiles, tile, splitk, d.workspace_bytes);
     // (a phase conv may split K like any other: its partial slabs are indexed by the LOW-resolution row and the reduce kernel scatters)
     if (splitk > 1)
@@ -1742,6 +1903,9 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
                         d.h_out == d.h_in && d.w_out == d.w_in && halo_rows_for(d.w_in) <= 384 &&
                         2 * halo_rows_for(d.w_in) * 128 + 3 * 128 * 128 + 1152 <= 160 * 1024))
         tile = 7;   // the halo kernel only does 3x3 / stride 1 / pad 1 on images up to 63 pixels wide, one K pass
+    if (tile == 17 && !(p.use_bl && p.stage_epi && p.splitk == 1 && d.ksize == 3 && d.stride == 1 && d.pad == 1 && !d.upsample && d.c1 == 0 &&
+                        d.h_out == d.h_in && d.w_out == d.w_in && d.epilogue != MVLDM_EPI_GEGLU && halow_smem(d.w_in) <= 160 * 1024))
+        tile = 7;   // the wide halo kernel: one-source 3x3 / stride 1 / pad 1 on maps up to 24 pixels wide, one K pass
     if (phase) {
         MVLDM_REQUIRE(p.use_bl && p.stage_epi, "igemm: 2x2 phase conv needs the lean 16-bit loop and an 8-aligned 16-bit output");
         if (tile != 7 && tile != 10) tile = 2;
@@ -1780,7 +1944,7 @@ static int fill_params(const mvldm_igemm_desc& d, IgemmParams& p, int& tile) {
         // MVLDM_IGEMM_GROUP=0 keeps the one-row / one-column order (A/B knob), "gm" forces the row count.
         p.grp_m = p.grp_n = 1;
         static const int kGroup = knob_int("MVLDM_IGEMM_GROUP", -1);
-        if (kGroup != 0 && tile >= 7 && tile <= 10 && p.sub_m * p.sub_n > 32) {
+        if (kGroup != 0 && ((tile >= 7 && tile <= 10) || tile == 17) && p.sub_m * p.sub_n > 32) {
             const double ax = a_bytes / p.px, wx = w_bytes / (8 / p.px);
             double bestc = 1e300;
             for (int gm = 1; gm <= 32; gm *= 2) {

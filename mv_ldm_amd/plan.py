@@ -621,7 +621,7 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
         small = rows < min_rows
         key = _igemm_signature(d) + (("sk",) if sk_pw is not None else ())
         best = _TUNE_CACHE.get(key)
-        if best is not None and (_unpack_choice(best)[0] & 63) not in (set(_TUNE_TILES) | set(_SMALL_TILES) | ({15} if sk_pw is not None else set())):
+        if best is not None and (_unpack_choice(best)[0] & 63) not in (set(_TUNE_TILES) | set(_SMALL_TILES) | {17} | ({15} if sk_pw is not None else set())):
             best = None          # an entry of an older build / another candidate set (a tile this build no longer offers): time it again
         if best is None:
             trial = L.Op()
@@ -633,6 +633,9 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
             cands = [(t, sk) for t in _TUNE_TILES for sk in _MID_SPLITS] if mid else [(t, None) for t in _TUNE_TILES] if not small else \
                     [(t, sk) for t in _SMALL_TILES if t in _TUNE_TILES or not os.environ.get("MVLDM_TUNE_TILES") for sk in (_SPLITS if can_split else (None,))]
             n_it = iters if not small else 3 * iters
+            if not small and 17 not in _TUNE_TILES and not os.environ.get("MVLDM_TUNE_TILES") and d.ksize == 3 and d.stride == 1 \
+                    and d.src1 is None and not d.upsample and d.w_in <= 24:
+                cands = cands + [(17, None)]     # the wide pixel-halo tile: one-source 3x3 convs on maps up to 24 wide (elsewhere it is tile 7)
             if sk_pw is not None:            # tile 15 in every configuration the library accepts for this problem (others return an error)
                 cands = cands + [(15 | (c << 8), 1) for c in _SKINNY_CFGS]
                 sk_ptr = sk_pw.skinny().data_ptr()

@@ -19,7 +19,7 @@ def resources():
 
 def test_report_covers_every_kernel_family(resources):
     names = " ".join(resources)
-    for fam in ("igemm_bl_kernel", "igemm_halo_kernel", "igemm_kernel", "linear_pp_kernel", "linear_pw_kernel", "linear_ws_kernel", "attention_kernel", "attention_bwd",
+    for fam in ("igemm_bl_kernel", "igemm_halo_kernel", "igemm_halow_kernel", "igemm_kernel", "linear_pp_kernel", "linear_pw_kernel", "linear_ws_kernel", "attention_kernel", "attention_bwd",
                 "wgrad_kernel", "gn_", "layernorm", "adamw"):
         assert fam in names, fam
     assert all("vgpr" in v and "scratch" in v for v in resources.values())
@@ -31,7 +31,7 @@ def test_hot_kernels_use_no_scratch(resources):
     registers, are no longer instantiated -- the library refuses that combination).  Forward attention is compiled to an
     occupancy target (4 / 3 / 2 waves per SIMD by head dim); since the K / V staging went to buffer descriptors (round 3) the
     kernels of the UNet's head dims (DP <= 64: d = 40, 64) are spill-free up to one register outside the loop."""
-    hot = re.compile(r"igemm_bl_kernelIDF16[b_]|igemm_halo_kernelIDF16[b_]|linear_pp_kernel|linear_pw_kernel|linear_ws_kernel|wgrad_dma_kernel|wgrad_kernelIDF16")
+    hot = re.compile(r"igemm_bl_kernelIDF16[b_]|igemm_halo_kernelIDF16[b_]|igemm_halow_kernelIDF16[b_]|linear_pp_kernel|linear_pw_kernel|linear_ws_kernel|wgrad_dma_kernel|wgrad_kernelIDF16")
     bad = {k: (v["scratch"], v.get("vgpr_spill", 0)) for k, v in resources.items()
            if hot.search(k) and (v["scratch"] or v.get("vgpr_spill", 0))}
     assert not bad, bad

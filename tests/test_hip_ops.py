@@ -881,6 +881,45 @@ def test_conv3x3_halo_tile(ops, dtype, n, c0, c1, cout, h, w):
     close(nchw(y), ref + rb.double()[:, :, None, None] + res.double(), dtype, "halo temb+residual")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,c0,cout,h,w", [(3, 64, 96, 5, 7), (9, 640, 640, 16, 16), (20, 128, 320, 8, 8), (40, 128, 64, 4, 4), (2, 64, 320, 20, 24),
+                                           (1, 64, 640, 3, 3)],
+                         ids=["odd_5x7", "L1_16x16", "8x8_spans_images", "many_4x4", "widest_24", "one_ragged_tile"])
+def test_conv3x3_wide_halo_tile(ops, dtype, n, c0, cout, h, w):
+    """tile 17: the pixel halo under a 256 x 320 tile (maps up to 24 pixels wide): image borders, tiles spanning several images, ragged
+    last row tile, column overhang (96 / 64 / 640 columns under 320-wide tiles), epilogues; bit-identical to the streaming kernels (same
+    K order); what it cannot take (two sources, a 32-wide map) silently runs as tile 7 -- same values"""
+    x = rnd((n, c0, h, w), 131, dtype)
+    wt = rnd((cout, c0, 3, 3), 133, dtype, 1 / math.sqrt(c0 * 9))
+    b = torch.randn(cout, generator=G(134)) * 0.1
+    rb = torch.randn(n, cout, generator=G(135))
+    res = rnd((n, cout, h, w), 136, dtype)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    xg = nhwc(x, dtype)
+    y = ops.conv2d(xg, pw, b.cuda(), tile=17, splitk=1)
+    close(nchw(y), ref, dtype, "wide halo")
+    assert torch.equal(y, ops.conv2d(xg, pw, b.cuda(), tile=7, splitk=1))
+    assert torch.equal(y, ops.conv2d(xg, pw, b.cuda(), tile=17, splitk=1))          # deterministic
+    y = ops.conv2d(xg, pw, b.cuda(), row_bias=rb.cuda(), residual=nhwc(res, dtype), epilogue=1 if cout == 96 else 0, tile=17, splitk=1)
+    want = ref + rb.double()[:, :, None, None]
+    want = (F.silu(want) if cout == 96 else want) + res.double()
+    close(nchw(y), want, dtype, "wide halo temb+residual")
+
+
+def test_wide_halo_tile_falls_back_where_it_does_not_apply(ops):
+    dtype = torch.bfloat16
+    x, x2 = rnd((2, 64, 32, 32), 141, dtype), rnd((2, 64, 8, 8), 142, dtype)
+    wt = rnd((320, 64, 3, 3), 143, dtype, 1 / 24)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    y = ops.conv2d(nhwc(x, dtype), pw, None, tile=17, splitk=1)                      # 32-wide map: 164 KB of LDS -> tile 7
+    assert torch.equal(y, ops.conv2d(nhwc(x, dtype), pw, None, tile=7, splitk=1))
+    wt2 = rnd((320, 128, 3, 3), 144, dtype, 1 / 34)
+    pw2 = ops.pack_weight(wt2.cuda(), dtype, c_split=64)
+    y = ops.conv2d(nhwc(x2, dtype), pw2, None, x2=nhwc(x2, dtype), tile=17, splitk=1)  # two sources -> tile 7
+    close(nchw(y), F.conv2d(torch.cat([x2, x2], 1).double(), wt2.double(), padding=1), dtype, "wide halo fallback")
+
+
 def test_empty_and_degenerate_inputs(ops):
     """zero images / rows / segments are no-ops (no launch, no error); one-pixel images and one-token sequences work;
     bad arguments are refused by the C side (negative return code -> exception), never silently computed elsewhere"""
