@@ -85,6 +85,8 @@ typedef struct mvldm_igemm_desc {
                            12 = persistent Linear with the epilogue pipelined under the next tile (linear_pp.hip: 1x1, one or two
                            sources, K >= 320 a multiple of 64, 16-bit in and out; any other problem is an error, not a fallback),
                            13 = persistent wide Linear (linear_pw.hip), 14 = weight-stationary Linear for K = 320 (linear_ws.hip),
+                           17 = 256 x 320 tile with the pixel halo resident in LDS (igemm.hip, round 5: one-source 3x3 / stride 1 / pad 1 convs
+                                on maps up to 24 pixels wide; anything else runs as tile 7, same values),
                            18 = 192 x 128 tile with a 4-slot ring (igemm.hip; 1x1 / 3x3, no upsampling forms, no GEGLU: refused),
                            15 = skinny-M weight-streaming GEMM (skinny.hip, round 5: launches of a few hundred rows -- one scene at the
                                 8x8 / 4x4 levels, mvunet.py:150-200 -- whose cost is the weight stream): `weight` is the FRAGMENT-ORDER
