@@ -574,8 +574,7 @@ template <int TAPS, int A_IT, bool DUAL, bool UPS> struct BlAddr {
 // issue K-tile (channel block cb, tap t) into the ring slot at `stage_base`
 // (STAGES is carried only to give every kernel instantiation its own copy: sharing one specialization
 //  between two kernels trips the host pass of hipcc 7.2)
-// PART: 0 = all pieces, 1 = the activation pieces, 2 = the weight pieces (the spread form of the 2-slot loop places them apart)
-template <typename T, int BM, int BN, int NW, int KS, bool DUAL, int A_IT, int B_IT, int STAGES, bool UPS, int t, int PART = 0>
+template <typename T, int BM, int BN, int NW, int KS, bool DUAL, int A_IT, int B_IT, int STAGES, bool UPS, int t>
 __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base, int wave, int cb,
                                          const BlAddr<KS * KS, A_IT, DUAL, UPS>& ad, const unsigned (&vb)[B_IT]) {
     constexpr int BK = 64, TAPS = KS * KS;
@@ -594,7 +593,7 @@ __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base,
     const bool from0 = !DUAL || c < p.c0;
     const int soff = ((from0 ? c : c - p.c0) + disp * (from0 ? p.c0 : p.c1)) * 2;
 #pragma unroll
-    for (int it = 0; it < (PART == 2 ? 0 : A_IT); ++it) {
+    for (int it = 0; it < A_IT; ++it) {
         __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024);
         unsigned v0, v1;
         if constexpr (UPS) {
@@ -610,7 +609,7 @@ __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base,
     }
     const int koff = (cb * TAPS + t) * (BK * 2);
 #pragma unroll
-    for (int it = 0; it < (PART == 1 ? 0 : B_IT); ++it)
+    for (int it = 0; it < B_IT; ++it)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(bt + (wave + NW * it) * 1024), 16,
                                                  vb[it], koff, 0, 0);
 }
@@ -797,43 +796,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
         slot_c ^= 1;                                                                                              \
     }
-    // 8-wave tiles on the 2-slot ring (tiles 9 / 10: one workgroup per CU, two waves per SIMD).  All 9 - 10 DMA pieces of a wave issued
-    // back to back behind the barrier keep BOTH waves of a SIMD in the address path while its matrix pipe idles (an LDS-DMA piece costs
-    // 60 - 185 issue cycles, MI355X_MICROARCH.md; the same finding as linear_pw.hip's two groups).  Here the activation pieces go out
-    // under the first sub-step's fragment reads, the weight pieces (L2-resident: shorter round trip) one sub-step later.
-#define MVLDM_BL_ISSUE_PART(stage_, cb_, t_, part_) \
-    bl_issue<T, BM, BN, NW, KS, DUAL, A_IT, B_IT, STAGES, UPS, t_, part_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, ad, vb)
-#define MVLDM_BL_STEP_SPREAD(t_)                                                                                  \
-    {                                                                                                             \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
-        __builtin_amdgcn_s_barrier();                                                                             \
-        const int cbn_ = cb + ((t_) + 1) / TAPS;                                                                  \
-        const char* sb_ = smem + slot_c * STAGE_BYTES;                                                            \
-        {                                                                                                         \
-            BlFrags<T, TM, TN> f;                                                                                 \
-            bl_load<T, BM, BN, WM, WN>(sb_, f, 0, wm, wn, hi, l31);                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if (cbn_ < cb1) { MVLDM_BL_ISSUE_PART(slot_c ^ 1, cbn_, MVLDM_BL_NEXT(t_, 1), 1); }                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            bl_mma<T, TM, TN>(f, acc);                                                                            \
-        }                                                                                                         \
-        {                                                                                                         \
-            BlFrags<T, TM, TN> f;                                                                                 \
-            bl_load<T, BM, BN, WM, WN>(sb_, f, 1, wm, wn, hi, l31);                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if (cbn_ < cb1) { MVLDM_BL_ISSUE_PART(slot_c ^ 1, cbn_, MVLDM_BL_NEXT(t_, 1), 2); }                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            bl_mma<T, TM, TN>(f, acc);                                                                            \
-        }                                                                                                         \
-        {                                                                                                         \
-            BlFrags<T, TM, TN> f;                                                                                 \
-            bl_load<T, BM, BN, WM, WN>(sb_, f, 2, wm, wn, hi, l31);                                               \
-            bl_mma<T, TM, TN>(f, acc);                                                                            \
-            bl_load<T, BM, BN, WM, WN>(sb_, f, 3, wm, wn, hi, l31);                                               \
-            bl_mma<T, TM, TN>(f, acc);                                                                            \
-        }                                                                                                         \
-        slot_c ^= 1;                                                                                              \
-    }
     // Deep ring (STAGES >= 4, the small-launch tiles 16 - 18): tiles t+1 .. t+STAGES-1 are in flight while tile t is consumed.  With a
     // few hundred output rows a K-tile is a handful of MFMAs, so a step of the 2-slot loop costs one exposed L2 / HBM round trip
     // (the 4x4-level convs of one scene: 18 steps x ~0.8 us for 30 MB of weights); here the round trip is shared by STAGES - 1 steps.
@@ -853,6 +815,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         if (cb0 + (j_) / TAPS < cb1) { MVLDM_BL_ISSUE((j_), cb0 + (j_) / TAPS, ((j_) % TAPS)); }                  \
     }
     // (the pipelined form needs 2 x (TM + TN) fragments next to the accumulators: not with 10 accumulator blocks)
+    // (round 5 re-tried it for tile 10 with the per-tap offsets kept out of registers: the 1x1 form fits -- and measures +-0 on every Linear --,
+    //  the 3x3 form still spills 52 B per lane into the loop: 870 -> 993 us)
     constexpr bool PIPE = NW == 8 && TM * TN <= 8 && STAGES <= 3;
     if constexpr (STAGES > 3) {
         static_assert((STAGES - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
@@ -874,20 +838,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         if (cb0 < cb1) {
             MVLDM_BL_ISSUE(0, cb0, 0);
             int slot_c = 0;
-#ifndef MVLDM_BL_SPREAD
-#define MVLDM_BL_SPREAD 0
-#endif
-            if constexpr (NW == 8 && MVLDM_BL_SPREAD) {
-                static_assert(64 / M_::KI == 4, "four k-sub-steps per K-tile");
-                for (int cb = cb0; cb < cb1; ++cb) {
-                    MVLDM_BL_STEP_SPREAD(0)
-                    if constexpr (TAPS == 4) { MVLDM_BL_STEP_SPREAD(1) MVLDM_BL_STEP_SPREAD(2) MVLDM_BL_STEP_SPREAD(3) }
-                    if constexpr (TAPS == 9) {
-                        MVLDM_BL_STEP_SPREAD(1) MVLDM_BL_STEP_SPREAD(2) MVLDM_BL_STEP_SPREAD(3) MVLDM_BL_STEP_SPREAD(4)
-                        MVLDM_BL_STEP_SPREAD(5) MVLDM_BL_STEP_SPREAD(6) MVLDM_BL_STEP_SPREAD(7) MVLDM_BL_STEP_SPREAD(8)
-                    }
-                }
-            } else
             for (int cb = cb0; cb < cb1; ++cb) {
                 MVLDM_BL_STEP_SIMPLE(0)
                 if constexpr (TAPS == 4) { MVLDM_BL_STEP_SIMPLE(1) MVLDM_BL_STEP_SIMPLE(2) MVLDM_BL_STEP_SIMPLE(3) }
@@ -922,8 +872,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         }
     }
 #undef MVLDM_BL_STEP_SIMPLE
-#undef MVLDM_BL_STEP_SPREAD
-#undef MVLDM_BL_ISSUE_PART
 #undef MVLDM_BL_STEP_DEEP
 #undef MVLDM_BL_PRO
 #undef MVLDM_BL_LOAD
@@ -1736,17 +1684,17 @@ template <typename T> static int launch_igemm(IgemmParams& p, int tile, hipStrea
                 if (p.use_bl) return launch_bl_any<T, 256, 256, 4, 2>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 9 needs the 16-bit block-major path");
-        case 10:
-            if constexpr (sizeof(T) == 2) {
-                if (p.use_bl) return launch_bl_any<T, 256, 320, 4, 2>(p, s);
-            }
-            return set_error(MVLDM_ERR_ARG, "igemm: tile 10 needs the 16-bit block-major path");
         case 11:
             if constexpr (sizeof(T) == 2) {
                 if (p.use_bl) return launch_halo<T>(p, s);
             }
             return set_error(MVLDM_ERR_ARG, "igemm: tile 11 needs the 16-bit block-major path");
 #endif
+        case 10:
+            if constexpr (sizeof(T) == 2) {
+                if (p.use_bl) return launch_bl_any<T, 256, 320, 4, 2>(p, s);
+            }
+            return set_error(MVLDM_ERR_ARG, "igemm: tile 10 needs the 16-bit block-major path");
         case 17:
             if constexpr (sizeof(T) == 2) {
                 if (p.use_bl) return launch_halow<T>(p, s);

@@ -3,10 +3,13 @@
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from mv_ldm_amd import _lib as L
+if '--lib' in sys.argv:      # another build of the library (experiment builds: same-box A/B)
+    L.LIB_PATH = L.LIB_PATH.with_name(sys.argv[sys.argv.index('--lib') + 1])
 from mv_ldm_amd import ops
 scenes = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
 n = 9 * scenes
-SH = [("L1 640->640 @16", 16, 640, 640), ("up2 1920->640 @16", 16, 1920, 640), ("up2 1280->640 @16", 16, 1280, 640), ("up2 960->640 @16", 16, 960, 640),
+SH = [("L0 320->320 @32", 32, 320, 320), ("up3 960->320 @32", 32, 960, 320), ("L1 640->640 @16", 16, 640, 640), ("up2 1920->640 @16", 16, 1920, 640), ("up2 1280->640 @16", 16, 1280, 640), ("up2 960->640 @16", 16, 960, 640),
       ("L1 320->640 @16", 16, 320, 640), ("L2 1280->1280 @8", 8, 1280, 1280), ("up1 2560->1280 @8", 8, 2560, 1280), ("up1 1920->1280 @8", 8, 1920, 1280),
       ("L2 640->1280 @8", 8, 640, 1280), ("L3 1280->1280 @4", 4, 1280, 1280)]
 rows = []
@@ -16,9 +19,11 @@ for name, h, c, co in SH:
     pw = ops.pack_weight(w, torch.bfloat16)
     b = torch.randn(co, device="cuda")
     res = {}
+    y7 = ops.conv2d(x, pw, b, splitk=1, tile=7)
     for tile in (7, 9, 10, 11, 17):
         f = lambda: ops.conv2d(x, pw, b, splitk=1, tile=tile)
-        f(); torch.cuda.synchronize()
+        assert torch.equal(f(), y7), (name, tile)      # same K order in every tile: bit-identical
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10): f()

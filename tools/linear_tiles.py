@@ -3,6 +3,9 @@ python tools/linear_tiles.py [scenes] [dtype] [tiles, e.g. 0,9,12]  -> one JSON 
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from mv_ldm_amd import _lib as L
+if '--lib' in sys.argv:      # another build of the library (experiment builds: same-box A/B)
+    i = sys.argv.index('--lib'); L.LIB_PATH = L.LIB_PATH.with_name(sys.argv[i + 1]); del sys.argv[i:i + 2]
 from mv_ldm_amd import ops
 
 scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 64
