@@ -21,3 +21,9 @@ for d in b64 b1 pmc; do
   rm -rf $O/$d
 done
 cp profiles/r05_kernel_stats.csv profiles/r05_mfma_util.json profiles/r05_b1_timeline.json $O/ 2>/dev/null
+# 4. HBM-side traffic per kernel family (two PMC passes of their own), trial-free: the last 192 igemm dispatches = the eager UNet pass
+P=/tmp/r05pmc; rm -rf $P
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/f -o p -- python3 bench.py --unet-pass-only > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/w -o p -- python3 bench.py --unet-pass-only > /dev/null 2>&1
+python3 tools/pmc_traffic.py $(find $P/f -name p_counter_collection.csv | head -1) $(find $P/w -name p_counter_collection.csv | head -1) profiles/pmc_traffic.json 192 bf16_b64_res256 "round 5 (tools/r05_profiles.sh), the last 192 igemm dispatches of bench.py --unet-pass-only, plans from the round's tune cache (no trials)" | tee $O/pmc_traffic.txt
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
