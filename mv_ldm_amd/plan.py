@@ -588,6 +588,22 @@ def _unpack_choice(v):
     return (int(v), None) if isinstance(v, int) else (int(v[0]), None if v[1] is None else int(v[1]))
 
 
+# Launches of at most MVLDM_TUNE_COLD output rows (default 9216; 0: never) are timed with COLD caches: a 640 MB fill runs in front of every
+# trial launch.  Back-to-back trials of a small op find its weights and inputs in the L2 of the XCD that read them a moment ago; inside a DDIM
+# step 1.85 GB of other weights pass between two uses of a layer and its input was written by the CUs of other XCDs (it comes from the
+# Infinity Cache at best).  Hot trials rank the tiles of the one-scene step wrongly: same box, one scene 5.14 -> 4.93 ms per DDIM step,
+# four scenes 9.84 -> 9.67, sixteen 27.85 -> 27.72; at 64 scenes cold trials for EVERY op measure 0.3 % slower than hot ones (large ops do
+# find their operands where a back-to-back trial finds them), hence the row bound.
+_TUNE_COLD = int(os.environ.get("MVLDM_TUNE_COLD", "9216"))
+_THRASH = []
+
+
+def _thrash():
+    if not _THRASH:
+        _THRASH.append(torch.empty(640 << 20, dtype=torch.uint8, device=torch.cuda.current_device()))      # > 2 x the 256 MB Infinity Cache
+    return _THRASH[0]
+
+
 def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=None, keep=None) -> int:
     """set `desc.tile` of every auto-tiled 16-bit block-major igemm op with >= `min_rows` output rows to the
     fastest candidate; returns the number of distinct problems timed.  `srcs`: {op index: (x, x2)} source tensors of
@@ -633,6 +649,7 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
             cands = [(t, sk) for t in _TUNE_TILES for sk in _MID_SPLITS] if mid else [(t, None) for t in _TUNE_TILES] if not small else \
                     [(t, sk) for t in _SMALL_TILES if t in _TUNE_TILES or not os.environ.get("MVLDM_TUNE_TILES") for sk in (_SPLITS if can_split else (None,))]
             n_it = iters if not small else 3 * iters
+            cold = _TUNE_COLD > 0 and rows <= _TUNE_COLD
             if not small and 17 not in _TUNE_TILES and not os.environ.get("MVLDM_TUNE_TILES") and d.ksize == 3 and d.stride == 1 \
                     and d.src1 is None and not d.upsample and d.w_in <= 24:
                 cands = cands + [(17, None)]     # the wide pixel-halo tile: one-source 3x3 convs on maps up to 24 wide (elsewhere it is tile 7)
@@ -645,6 +662,19 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
                 trial.u.igemm.splitk = d.splitk if sk is None else sk
                 trial.u.igemm.weight, trial.u.igemm.k_order = (sk_ptr, 2) if (tile & 63) == 15 else (d.weight, d.k_order)
                 if lib.mvldm_op_run(C.byref(trial), stream) != 0:      # candidate not applicable to this problem
+                    continue
+                if cold:
+                    # weight-bound launches (a few scenes): inside a DDIM step 1.85 GB of other weights pass between two uses of a layer, so
+                    # its weights come from HBM; back-to-back trials would read them from the Infinity Cache and rank the tiles differently
+                    t_sum = 0.0
+                    for _ in range(n_it):
+                        _thrash().zero_()
+                        e0.record()
+                        lib.mvldm_op_run(C.byref(trial), stream)
+                        e1.record()
+                        e1.synchronize()
+                        t_sum += e0.elapsed_time(e1)
+                    results.append((t_sum, tile, sk))
                     continue
                 e0.record()
                 for _ in range(n_it):
