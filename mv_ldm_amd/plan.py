@@ -593,7 +593,8 @@ def _unpack_choice(v):
 # step 1.85 GB of other weights pass between two uses of a layer and its input was written by the CUs of other XCDs (it comes from the
 # Infinity Cache at best).  Hot trials rank the tiles of the one-scene step wrongly: same box, one scene 5.14 -> 4.93 ms per DDIM step,
 # four scenes 9.84 -> 9.67, sixteen 27.85 -> 27.72; at 64 scenes cold trials for EVERY op measure 0.3 % slower than hot ones (large ops do
-# find their operands where a back-to-back trial finds them), hence the row bound.
+# find their operands where a back-to-back trial finds them), hence the row bound.  (Cold trials of the weight-gradient forms and of the
+# training plans' igemm ops up to 40000 rows: 530 - 537 training views/s either way, not kept.)
 _TUNE_COLD = int(os.environ.get("MVLDM_TUNE_COLD", "9216"))
 _THRASH = []
 
