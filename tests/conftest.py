@@ -7,6 +7,11 @@ import numpy as np
 import pytest
 import torch
 
+# The plan-time tuner times small launches behind a 640 MB cache-flushing fill (plan._TUNE_COLD): right for the product, but it doubles
+# the wall time of a suite that records hundreds of tiny plans.  The suite runs the hot trials; ONE test turns the cold path on
+# (tests/test_hip_headline.py::test_cold_cache_tuning_path).  Must be set before mv_ldm_amd.plan is imported.
+os.environ.setdefault("MVLDM_TUNE_COLD", "0")
+
 ROOT = Path(__file__).resolve().parent.parent
 GOLDEN = ROOT / "tests" / "golden"
 for p in (str(ROOT), str(GOLDEN)):

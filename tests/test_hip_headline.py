@@ -167,6 +167,38 @@ def test_rule_based_tiles_match_the_tuned_plan(models, monkeypatch, dtype):
     assert torch.isfinite(outs["0"]).all() and e < (1e-5 if dtype == torch.float32 else 1e-2), e
 
 
+def test_cold_cache_tuning_path(models, monkeypatch):
+    """the product times launches of <= 9216 rows behind a cache-flushing fill (plan._TUNE_COLD; the suite default is hot trials, see
+    conftest): the one-scene plan recorded that way must equal the rule-based plan like any tuned plan does, and the fill must really
+    have run (its 640 MB buffer exists afterwards)"""
+    M, m, _ = models
+    from mv_ldm_amd import plan as P
+    v_c, v_t, b = 1, 4, 1
+    ctx_lat, x_t, extr, intr = _inputs(v_c, v_t, b=b, seed=13)
+    dtype = torch.bfloat16
+    outs = {}
+    saved = dict(P._TUNE_CACHE)
+    for mode in ("cold", "rules"):
+        monkeypatch.setenv("MVLDM_AUTOTUNE", "1" if mode == "cold" else "0")
+        monkeypatch.setattr(P, "_TUNE_COLD", 9216 if mode == "cold" else 0)
+        if mode == "cold":
+            P._TUNE_CACHE.clear()                      # every problem of this plan is timed again, cold
+            P._THRASH.clear()
+        pipe = _pipe(m)
+        with M.compute_dtype(dtype):
+            st = pipe._compile(b, v_c, v_t, 32, 32, dtype, 50)
+            pipe.load_inputs(st, ctx_lat, x_t, (extr[:, :v_c], intr[:, :v_c]), (extr[:, v_c:], intr[:, v_c:]))
+            st["plan"].replay()
+            outs[mode] = pipe._read_state(st, b, v_t).cpu()
+        if mode == "cold":
+            assert P._THRASH and P._THRASH[0].numel() >= (512 << 20)
+        pipe._plans.clear()
+    P._TUNE_CACHE.clear()
+    P._TUNE_CACHE.update(saved)
+    e = rel_err(outs["cold"], outs["rules"])
+    assert torch.isfinite(outs["cold"]).all() and e < 1e-2, e
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_shared_cfg_prefix_equals_the_two_pass_walk(models, monkeypatch, dtype):
     """the unconditional pass of classifier-free guidance re-submits the target views of the conditional pass; the layers in front
