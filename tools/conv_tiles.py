@@ -29,8 +29,21 @@ for name, h, c, co in SH:
         for _ in range(10): f()
         e1.record(); torch.cuda.synchronize()
         res[tile] = e0.elapsed_time(e1) * 100
+    if "--miopen" in sys.argv:
+        # yardstick: the vendor convolution (MIOpen through torch, channels-last bf16) on the same operands
+        xc = x.permute(0, 3, 1, 2)                     # NCHW view of the NHWC tensor = channels_last
+        wc = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        bc = b.to(torch.bfloat16)
+        f = lambda: torch.nn.functional.conv2d(xc, wc, bc, padding=1)
+        for _ in range(3): f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        res["miopen"] = e0.elapsed_time(e1) * 100
     fl = 2.0 * n * h * h * co * c * 9
-    rows.append({"name": name, "us": res, "tflops": {t: fl / u / 1e6 for t, u in res.items()}})
-    print(f"{name:22s} " + "  ".join(f"t{t}: {u:7.1f}us {fl / u / 1e6:5.0f}TF" for t, u in res.items()), flush=True)
+    rows.append({"name": name, "us": {str(t): u for t, u in res.items()}, "tflops": {str(t): fl / u / 1e6 for t, u in res.items()}})
+    print(f"{name:22s} " + "  ".join(f"{'t' + str(t) if isinstance(t, int) else t}: {u:7.1f}us {fl / u / 1e6:5.0f}TF" for t, u in res.items()), flush=True)
 if "--json" in sys.argv:
     json.dump(rows, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

@@ -46,4 +46,18 @@ for name, rows, k, nn, epi, res in SH:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         rec[f"t{tile}"] = [round(us), round(2.0 * rows * k * nn / us / 1e6)]
+    if "--blas" in sys.argv:
+        # yardstick: the vendor GEMM (hipBLASLt through torch) on the same operands.  Plain GEMM + bias only -- no GEGLU product, no residual
+        # add: its number is what the library needs for LESS work than the fused launch above does.
+        wt = w.to(dtype)
+        f = lambda: torch.nn.functional.linear(x, wt, b.to(dtype))
+        f(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        rec["hipblaslt_gemm_bias_only"] = [round(us), round(2.0 * rows * k * nn / us / 1e6)]
     print(json.dumps(rec), flush=True)
