@@ -167,6 +167,29 @@ def test_rule_based_tiles_match_the_tuned_plan(models, monkeypatch, dtype):
     assert torch.isfinite(outs["0"]).all() and e < (1e-5 if dtype == torch.float32 else 1e-2), e
 
 
+def test_fused_step_with_the_wide_halo_tile_pinned(models, monkeypatch):
+    """`MVLDM_IGEMM_TILE=17` sends EVERY 16-bit conv / Linear of the fused CFG step to tile 17: the one-source 3x3 convs of the 16x16 and
+    smaller levels run the wide pixel-halo kernel, everything else (1x1, Linears, 32x32 maps, two sources, phase convs) must fall back
+    to a streaming tile with the same values -- the step equals the plan pinned to tile 7 bit for bit (same K order, one K pass in both)"""
+    M, m, _ = models
+    v_c, v_t, b = 1, 4, 2
+    ctx_lat, x_t, extr, intr = _inputs(v_c, v_t, b=b, seed=17)
+    dtype = torch.bfloat16
+    outs = {}
+    for tile in ("17", "7"):
+        monkeypatch.setenv("MVLDM_IGEMM_TILE", tile)
+        pipe = _pipe(m)
+        with M.compute_dtype(dtype):
+            st = pipe._compile(b, v_c, v_t, 32, 32, dtype, 50)
+            pipe.load_inputs(st, ctx_lat, x_t, (extr[:, :v_c], intr[:, :v_c]), (extr[:, v_c:], intr[:, v_c:]))
+            st["plan"].replay()
+            outs[tile] = pipe._read_state(st, b, v_t).cpu()
+        if tile == "17":
+            assert any(t == 17 for t in st["plan"].tiles if t is not None)
+        pipe._plans.clear()
+    assert torch.isfinite(outs["17"]).all() and torch.equal(outs["17"], outs["7"])
+
+
 def test_cold_cache_tuning_path(models, monkeypatch):
     """the product times launches of <= 9216 rows behind a cache-flushing fill (plan._TUNE_COLD; the suite default is hot trials, see
     conftest): the one-scene plan recorded that way must equal the rule-based plan like any tuned plan does, and the fill must really
