@@ -88,6 +88,9 @@ typedef struct mvldm_igemm_desc {
                            17 = 256 x 320 tile with the pixel halo resident in LDS (igemm.hip, round 5: one-source 3x3 / stride 1 / pad 1 convs
                                 on maps up to 24 pixels wide; anything else runs as tile 7, same values),
                            18 = 192 x 128 tile with a 4-slot ring (igemm.hip; 1x1 / 3x3, no upsampling forms, no GEGLU: refused),
+                           19 = register-staged persistent Linear (linear_rs.hip, round 6: 256 x 256 tiles, 4 waves of 128 x 128, the K-steps in
+                                flight held in registers; 1x1, one or two sources, K >= 256 a multiple of 128, 16-bit in and out, bias /
+                                residual / GEGLU; any other problem is an error, not a fallback),
                            15 = skinny-M weight-streaming GEMM (skinny.hip, round 5: launches of a few hundred rows -- one scene at the
                                 8x8 / 4x4 levels, mvunet.py:150-200 -- whose cost is the weight stream): `weight` is the FRAGMENT-ORDER
                                 pack of mvldm_pack_skinny (k_order must be 2), whole K per workgroup, no split-K slab and no reduce launch;

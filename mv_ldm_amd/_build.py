@@ -12,7 +12,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libmvldm_hip.so"
 SOURCES = ["api.cpp", "plan.cpp", "igemm.hip", "attention.hip", "norm.hip", "misc.hip",
-           "wgrad.hip", "attention_bwd.hip", "norm_bwd.hip", "train_misc.hip", "linear_pp.hip", "linear_pw.hip", "linear_ws.hip", "skinny.hip"]
+           "wgrad.hip", "attention_bwd.hip", "norm_bwd.hip", "train_misc.hip", "linear_pp.hip", "linear_pw.hip", "linear_ws.hip", "linear_rs.hip", "skinny.hip"]
 HEADERS = [CSRC / "common.h", CSRC / "reduce.h", CSRC.parent.parent / "include" / "mvldm.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result",
          "-Rpass-analysis=kernel-resource-usage"]          # per-kernel registers / scratch -> csrc/kernel_resources.json

@@ -1911,6 +1911,7 @@ int linear_pp_run(const mvldm_igemm_desc& d, hipStream_t s);
 int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s);
 int linear_ws_run(const mvldm_igemm_desc& d, hipStream_t s);      // tile 14: weight-stationary Linear for K = 320 (linear_ws.hip)
 int skinny_run(const mvldm_igemm_desc& d, hipStream_t s);         // tile 15: skinny-M weight-streaming GEMM on the fragment-order pack (skinny.hip)
+int linear_rs_run(const mvldm_igemm_desc& d, hipStream_t s);      // tile 19: register-staged persistent Linear, 4 waves of 128 x 128 (linear_rs.hip)
 
 int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
     IgemmParams p;
@@ -1929,6 +1930,10 @@ int igemm_run(const mvldm_igemm_desc& d, hipStream_t s) {
         return linear_ws_run(d, s);
     }
     if ((d.tile & 63) == 15) return skinny_run(d, s);
+    if ((d.tile & 63) == 19) {
+        MVLDM_REQUIRE(d.src0 && d.weight && d.dst, "igemm: null pointer");
+        return linear_rs_run(d, s);
+    }
     MVLDM_REQUIRE(d.k_order != 2, "igemm: the fragment-order pack (k_order 2) is read by tile 15 only");
     int rc = fill_params(d, p, tile);
     if (rc) return rc;

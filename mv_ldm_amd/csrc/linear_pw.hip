@@ -40,7 +40,7 @@ struct LinPWParams {
     const void* a; const void* a1; const void* w; const float* bias; const void* residual; void* dst;
     int M, K, c0, c1, kt0, n_out, n_pad, n_dst, dst_ld, k_steps;    // K = c0 + c1; K-steps [0, kt0) come from `a`, the rest from `a1`
     int tiles_m, tiles_n, m_per;       // m_per: 256-row blocks per XCD
-    int gm, gn, nbn;                   // an XCD's workgroups cover gm x gn blocks of tiles, column chunks (nbn of them) fastest
+    int gm, gn, nbn, wgx;              // an XCD's wgx workgroups walk its tiles in gm x gn blocks, column chunks (nbn of them) fastest
     int nt_store;
     float out_scale;
     unsigned a_bytes, a1_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
@@ -205,21 +205,30 @@ __device__ __forceinline__ unsigned pw_off(unsigned row, int col, int n_dst) {
     return (row != kPwRowNone && col < n_dst) ? row + (unsigned)col * 2u : kPwOob;
 }
 
-// Walks the tiles of a workgroup (all wave-uniform).  XCD x owns row blocks [x * m_per, (x+1) * m_per) and all column tiles; its gm * gn
-// workgroups cover one gm x gn BLOCK of tiles per round (workgroup lid: row lid % gm, column lid / gm of the block), column chunks
-// fastest: the workgroups an XCD runs at the same time share gm activation row blocks and gn weight panels in its L2 (with one row of
-// 32 column tiles in flight the 6.5 MB weight of the level-1 GEGLU projection streamed through the 4 MB L2 once per row block), and a
-// workgroup's consecutive tiles re-read ITS row block while it is still there.
+// Walks the tiles of a workgroup (all wave-uniform).  XCD x owns row blocks [x * m_per, (x+1) * m_per) and all column tiles.  Its tiles
+// form ONE list in block order -- gm x gn blocks of tiles, column chunks (nbn of them) fastest, inside a block the row fastest; ragged
+// blocks at the edges are packed densely -- and its wgx workgroups take list entries lid, lid + wgx, lid + 2 wgx ...: the workgroups an XCD
+// runs at the same time share about gm activation row blocks and gn weight panels in its L2 (with one row of 32 column tiles in flight the
+// 6.5 MB weight of the level-1 GEGLU projection streamed through the 4 MB L2 once per row block), and a round leaves no CU idle unless
+// the list ends.  (Rounds 4-5 walked whole blocks, one per round: a block shape that did not divide the XCD's tile grid idled workgroups
+// in EVERY round -- 27 of 32 on the 8 x 8 level QKV, 8 rounds for 6.75 rounds of work.)
 struct PwTileIter {
     int r, tm, tn;
     bool valid;
-    __device__ __forceinline__ void set(const LinPWParams& p, int r0, int lm, int ln, int m_lo, int m_cnt, int rounds) {
-        valid = false;
-        for (r = r0; r < rounds; ++r) {
-            const int sm = r / p.nbn, cn = r - sm * p.nbn;
-            const int tml = sm * p.gm + lm;
+    __device__ __forceinline__ void set(const LinPWParams& p, int r0, int lid, int m_lo, int m_cnt) {
+        r = r0;
+        const int i = r0 * p.wgx + lid;
+        valid = i < m_cnt * p.tiles_n;
+        if (valid) {
+            const int strip = p.gm * p.tiles_n;                          // tiles of a full strip of gm row blocks
+            const int sm = min(i / strip, (m_cnt + p.gm - 1) / p.gm - 1);
+            const int hm = min(p.gm, m_cnt - sm * p.gm);                 // rows of this strip (the last one may be lower)
+            const int is = i - sm * strip;
+            const int cn = is / (hm * p.gn);                             // column chunk (the last one may be narrower)
+            const int j = is - cn * hm * p.gn;
+            const int ln = j / hm;
+            tm = m_lo + sm * p.gm + (j - ln * hm);
             tn = cn * p.gn + ln;
-            if (tml < m_cnt && tn < p.tiles_n) { tm = m_lo + tml; valid = true; break; }
         }
     }
 };
@@ -261,12 +270,10 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
 
     const int xcd = blockIdx.x & 7, lid = blockIdx.x >> 3;
     const int m_lo = xcd * p.m_per, m_cnt = min(p.tiles_m, m_lo + p.m_per) - m_lo;
-    const int rounds = m_cnt > 0 ? ((m_cnt + p.gm - 1) / p.gm) * p.nbn : 0;
-    const int lm = lid % p.gm, ln = lid / p.gm;
     PwTileIter cur, nxt, iss;                    // compute side, the tile after it, issue side (newest ring step in flight)
-    cur.set(p, 0, lm, ln, m_lo, m_cnt, rounds);
+    cur.set(p, 0, lid, m_lo, m_cnt);
     if (!cur.valid) return;
-    nxt.set(p, cur.r + 1, lm, ln, m_lo, m_cnt, rounds);
+    nxt.set(p, cur.r + 1, lid, m_lo, m_cnt);
     iss = cur;
 
     u32x4 rdst;
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
             if (DMA_ && j == 0) {                                                                                 \
                 if (++ks_i == kT) {                                                                               \
                     ks_i = 0;                                                                                     \
-                    iss.set(p, iss.r + 1, lm, ln, m_lo, m_cnt, rounds);                                           \
+                    iss.set(p, iss.r + 1, lid, m_lo, m_cnt);                                                  \
                     pw_offsets<TN>(p, iss.valid, iss.tm, iss.tn, wave, lane, ad);                                 \
                 }                                                                                                 \
                 pw_issue_a<TN>(p, smem, rs, wave, lane, ks_i, ad);                                                \
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
     constexpr int kWaitFirst = pw_wait(4 * NOUT) & ~0x0F00;      // step 1 of the tile has landed: everything but the previous epilogue's 4 * NOUT stores
     constexpr int kWaitStep = pw_wait(0) & ~0x0F00;              // vmcnt(0) lgkmcnt(0): step g+1 has landed (and every older store)
 
-    for (; cur.valid; cur = nxt, nxt.set(p, nxt.r + 1, lm, ln, m_lo, m_cnt, rounds)) {
+    for (; cur.valid; cur = nxt, nxt.set(p, nxt.r + 1, lid, m_lo, m_cnt)) {
         // ---- the tile starts from its bias (slab written in the prologue / the previous epilogue, published by this barrier).  Steps 0
         //      and 1 found their pieces retired by the epilogue's (the prologue's) load wait ----
         __builtin_amdgcn_s_barrier();
@@ -497,14 +504,33 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     p.dst_ld = d.dst_ld > 0 ? d.dst_ld : p.n_dst;
     p.k_steps = p.K / 64; p.out_scale = d.out_scale;
     // 256 x 320 when the packed width is a multiple of 320 (every channel count of this UNet), else 256 x 256; GEGLU pairs need an even
-    // number of column blocks per wave
+    // number of column blocks per wave.  Round 6: ... unless 256 x 256 tiles need clearly fewer MFMA cycles per CU -- a launch lasts
+    // rounds x tile area, rounds = ceil(tiles of the XCD / its 32 CUs): the 8 x 8 level's N = 1280 Linears (36 864 rows: 72 tiles of
+    // 256 x 320 per XCD = 2.25 rounds, run as 3) take 3 rounds of the SMALLER tile instead (90 tiles = 2.8 rounds), -20 %.
     const bool geglu = d.epilogue == MVLDM_EPI_GEGLU;
     static const int kForceTn = knob_int("MVLDM_PW_TN", 0);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
+        else
+            n_cu = 256;
+    }
+    const int cu_x = std::max(1, n_cu / 8);
+    p.tiles_m = (p.M + PW_BM - 1) / PW_BM;
+    p.m_per = (p.tiles_m + 7) / 8;
+    auto launch_cost = [&](int tnb) {      // MFMA time of the busiest CU, in 256 x 64-column units
+        const int tiles = p.m_per * ((d.n_pad + 64 * tnb - 1) / (64 * tnb));
+        const int wg = std::min(cu_x, tiles);
+        return (double)((tiles + wg - 1) / wg) * tnb;
+    };
     int tn_blocks = (!geglu && d.n_pad % 320 == 0) ? 5 : 4;
+    if (tn_blocks == 5 && launch_cost(4) < 0.95 * launch_cost(5)) tn_blocks = 4;
     if (kForceTn == 4 || (kForceTn == 5 && !geglu)) tn_blocks = kForceTn;
     const int bn = 64 * tn_blocks;
-    p.tiles_m = (p.M + PW_BM - 1) / PW_BM; p.tiles_n = (d.n_pad + bn - 1) / bn;
-    p.m_per = (p.tiles_m + 7) / 8;
+    p.tiles_n = (d.n_pad + bn - 1) / bn;
     p.a_bytes = (unsigned)((double)p.M * p.c0 * 2.0); p.a1_bytes = (unsigned)((double)p.M * p.c1 * 2.0); p.w_bytes = (unsigned)((double)d.n_pad * d.k_pad * 2.0);
     p.bias_bytes = d.bias ? (unsigned)d.n_out * 4u : 0u;
     p.res_bytes = d.residual ? (unsigned)((double)p.M * p.n_dst * 2.0) : 0u;
@@ -515,37 +541,23 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     if (kPwFake & 1) p.a_bytes = p.a1_bytes = 0;
     if (kPwFake & 2) p.w_bytes = 0;
     if (kPwFake & 4) p.dst_bytes = 0;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n_cu = prop.multiProcessorCount;
-        else
-            n_cu = 256;
-    }
-    // An XCD's workgroups (one per CU, fewer when it has fewer tiles) cover gm x gn blocks of tiles, round after round: the shape with
-    // (within 3 % of) the fewest rounds that moves the fewest bytes into the XCD's L2 per round -- gm activation row blocks + gn weight panels
-    const int cu_x = std::max(1, n_cu / 8);
+    // An XCD's workgroups (one per CU, fewer when it has fewer tiles) walk its tile list, which is ordered in gm x gn blocks (PwTileIter):
+    // the block shape of about one round's tiles that moves the fewest bytes into the XCD's L2 per round -- gm activation row blocks + gn
+    // weight panels
     const double a_t = 256.0 * p.K * 2.0, w_t = (double)bn * p.K * 2.0;
-    int best_rounds = 1 << 30;
-    for (int gm = 1; gm <= std::min(cu_x, p.m_per); ++gm)
-        for (int gn = 1; gn <= std::min(cu_x / gm, p.tiles_n); ++gn)
-            best_rounds = std::min(best_rounds, ((p.m_per + gm - 1) / gm) * ((p.tiles_n + gn - 1) / gn));
+    p.wgx = std::min(cu_x, p.m_per * p.tiles_n);
     double best_cost = 1e300;
     p.gm = p.gn = 1;
-    for (int gm = 1; gm <= std::min(cu_x, p.m_per); ++gm)
-        for (int gn = 1; gn <= std::min(cu_x / gm, p.tiles_n); ++gn) {
-            const int r = ((p.m_per + gm - 1) / gm) * ((p.tiles_n + gn - 1) / gn);
-            if (r > best_rounds * 1.03) continue;
-            const double cost = gm * a_t + gn * w_t;
-            if (cost < best_cost) { best_cost = cost; p.gm = gm; p.gn = gn; }
-        }
+    for (int gm = 1; gm <= std::min(p.wgx, p.m_per); ++gm) {
+        const int gn = std::max(1, std::min(p.wgx / gm, p.tiles_n));
+        // (cost per tile of the block: a block smaller than a round shares less)
+        const double cost = (gm * a_t + gn * w_t) / (gm * gn);
+        if (cost < best_cost) { best_cost = cost; p.gm = gm; p.gn = gn; }
+    }
     static const int kForceGm = knob_int("MVLDM_PW_GM", 0);   // tuning: force the block shape
-    if (kForceGm > 0) { p.gm = std::min(std::min(kForceGm, cu_x), p.m_per); p.gn = std::max(1, std::min(cu_x / p.gm, p.tiles_n)); }
+    if (kForceGm > 0) { p.gm = std::min(std::min(kForceGm, p.wgx), p.m_per); p.gn = std::max(1, std::min(p.wgx / p.gm, p.tiles_n)); }
     p.nbn = (p.tiles_n + p.gn - 1) / p.gn;
-    const int wpx = p.gm * p.gn;
-    const int grid = 8 * wpx;
+    const int grid = 8 * p.wgx;
     const bool res = d.residual != nullptr;
     return dispatch_dtype(d.act_dtype, [&](auto t) -> int {
         using T = decltype(t);

@@ -591,6 +591,99 @@ def test_wide_persistent_tile_in_place_residual(ops):
     close(y.float().cpu().double(), F.linear(x.double(), wt.double()) + h.double(), dtype, "in-place residual tile13")
 
 
+# ---- tile 19 (round 6): register-staged persistent Linear, 4 waves of 128 x 128 (csrc/linear_rs.hip) ----------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,cin,cout", [(300, 256, 320), (1000, 384, 960), (2500, 640, 200), (70000, 256, 64), (20000, 1280, 328),
+                                           (66000, 512, 640), (40001, 640, 1280), (9216, 5120, 1280)])
+def test_linear_register_staged_tile(ops, dtype, rows, cin, cout):
+    """tile 19 (linear_rs.hip: persistent 256 x 256 tiles, two K-steps of operands in flight in registers, 2-slot LDS ring written by
+    ds_write_b128, epilogue straight from the accumulators): ragged M / N, 4 .. 80 K-steps, more tiles than workgroups and fewer,
+    residual and none, no bias"""
+    x, wt = rnd((rows, cin), 41, dtype), rnd((cout, cin), 42, dtype, 1 / math.sqrt(cin))
+    b = torch.randn(cout, generator=G(43)) * 0.1
+    res = rnd((rows, cout), 44, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    lin = F.linear(x.double(), wt.double(), b.double())
+    xg = x.to(dtype).cuda()
+    y = ops.linear(xg, pw, b.cuda(), residual=res.to(dtype).cuda(), tile=19)
+    close(y.float().cpu().double(), lin + res.double(), dtype, "linear+res tile19")
+    y = ops.linear(xg, pw, None, tile=19)
+    close(y.float().cpu().double(), F.linear(x.double(), wt.double()), dtype, "linear nobias tile19")
+    y = ops.linear(xg, pw, b.cuda(), tile=19)
+    close(y.float().cpu().double(), lin, dtype, "linear tile19")
+    y0 = ops.linear(xg, pw, b.cuda(), tile=7)       # same MFMA K order; the bias enters last here
+    assert (y.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
+    assert (y != y0).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("rows,c", [(300, 256), (33000, 384), (5000, 640), (9216, 1280)])
+def test_geglu_register_staged_tile(ops, dtype, rows, c):
+    """tile 19 with the GEGLU pairing: value and gate of a column sit in the same lane (same row permutation for both blocks)"""
+    x, wt = rnd((rows, c), 45, dtype), rnd((8 * c, c), 46, dtype, 1 / math.sqrt(c))
+    b = torch.randn(8 * c, generator=G(47)) * 0.1
+    pw = ops.pack_weight(wt.cuda(), dtype, geglu=True)
+    a, g = F.linear(x.double(), wt.double(), b.double()).chunk(2, -1)
+    y = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=19)
+    assert y.shape == (rows, 4 * c)
+    close(y.float().cpu().double(), a * F.gelu(g), dtype, "geglu tile19")
+    y7 = ops.linear(x.to(dtype).cuda(), pw, b.cuda(), epilogue=2, tile=7)
+    assert (y.float() - y7.float()).abs().max().item() <= 2e-2 * y7.float().abs().max().item()
+    assert (y != y7).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("n,h,c0,c1,cout", [(3, 16, 320, 320, 320), (5, 8, 640, 384, 640), (2, 32, 64, 576, 200), (9, 8, 1280, 1280, 1280)])
+def test_register_staged_tile_two_sources(ops, dtype, n, h, c0, c1, cout):
+    """tile 19 on the 1x1 shortcut conv of an up-block resnet (never-materialised channel concat): K-steps [0, c0/64) stream from the
+    first tensor, the rest from the second (the switch may fall on an odd step)"""
+    x, x2 = rnd((n, c0, h, h), 51, dtype), rnd((n, c1, h, h), 52, dtype)
+    w = rnd((cout, c0 + c1), 53, dtype, 1 / math.sqrt(c0 + c1))
+    b = torch.randn(cout, generator=G(54)) * 0.1
+    pw = ops.pack_weight(w.cuda(), dtype, c_split=c0)
+    ref = F.conv2d(torch.cat([x, x2], 1).double(), w.double()[:, :, None, None], b.double())
+    y = ops.conv2d(nhwc(x, dtype), pw, b.cuda(), x2=nhwc(x2, dtype), tile=19)
+    close(nchw(y), ref, dtype, "dual-source 1x1 tile19")
+
+
+def test_register_staged_tile_race_screen_and_refusals(ops):
+    """tile 19 keeps two K-steps in flight in registers across tile boundaries and through the epilogue's loads and stores, all in one
+    in-order queue counted by the compiler: the same launch, repeated while another stream keeps the memory system busy, must be
+    bit-identical every time.  In place (x += f(x)).  An odd number of K-steps / K < 256 / an activation epilogue are errors."""
+    import mv_ldm_amd._lib as L
+    torch.manual_seed(0)
+    side, noise = torch.cuda.Stream(), torch.randn(16 << 20, device="cuda")
+    for rows, k, n, epi, res in ((36864, 1280, 10240, 2, False), (70001, 384, 200, 0, True), (36864, 5120, 1280, 0, True),
+                                 (147456, 640, 1920, 0, False)):
+        x = torch.randn(rows, k, device="cuda").to(torch.bfloat16)
+        pw = ops.pack_weight(torch.randn(n, k, device="cuda") / k ** 0.5, torch.bfloat16, geglu=epi == 2)
+        b = torch.randn(n, device="cuda")
+        r = torch.randn(rows, n, device="cuda").to(torch.bfloat16) if res else None
+        ref = ops.linear(x, pw, b, residual=r, epilogue=epi, tile=19).clone()
+        ref7 = ops.linear(x, pw, b, residual=r, epilogue=epi, tile=7)
+        assert (ref.float() - ref7.float()).abs().max().item() <= 2e-2 * ref7.float().abs().max().item()
+        for i in range(30):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    noise.mul_(1.0001)
+            assert torch.equal(ops.linear(x, pw, b, residual=r, epilogue=epi, tile=19), ref), (rows, i)
+    torch.cuda.synchronize()
+    dtype = torch.bfloat16
+    x, wt = rnd((30000, 640), 61, dtype), rnd((640, 640), 62, dtype, 1 / math.sqrt(640))
+    h = rnd((30000, 640), 63, dtype)
+    pw = ops.pack_weight(wt.cuda(), dtype)
+    hg = h.to(dtype).cuda()
+    y = ops.linear(x.to(dtype).cuda(), pw, None, residual=hg, out=hg, tile=19)
+    close(y.float().cpu().double(), F.linear(x.double(), wt.double()) + h.double(), dtype, "in-place residual tile19")
+    xs = torch.randn(512, 320, device="cuda").to(dtype)
+    with pytest.raises(L.MvldmError):     # 5 K-steps
+        ops.linear(xs, ops.pack_weight(torch.randn(320, 320, device="cuda"), dtype), tile=19)
+    with pytest.raises(L.MvldmError):     # K = 128
+        ops.linear(xs[:, :128].contiguous(), ops.pack_weight(torch.randn(320, 128, device="cuda"), dtype), tile=19)
+    with pytest.raises(L.MvldmError):     # SiLU epilogue
+        ops.linear(x.to(dtype).cuda(), pw, None, epilogue=1, tile=19)
+
+
 def test_persistent_tile_race_screen(ops):
     """the counted-vmcnt ring, the prefetch across tile boundaries and the asm stores of tile 12 are the kind of code whose
     hazards show up as RARE wrong tiles: the same launch, repeated while another stream keeps the memory system busy, must be
