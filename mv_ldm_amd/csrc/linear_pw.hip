@@ -41,10 +41,18 @@ struct LinPWParams {
     int M, K, c0, c1, kt0, n_out, n_pad, n_dst, dst_ld, k_steps;    // K = c0 + c1; K-steps [0, kt0) come from `a`, the rest from `a1`
     int tiles_m, tiles_n, m_per;       // m_per: 256-row blocks per XCD
     int gm, gn, nbn, wgx;              // an XCD's wgx workgroups walk its tiles in gm x gn blocks, column chunks (nbn of them) fastest
-    int nt_store;
+    int nt_store, touch, stagger;      // touch: L2 prefetch of the activation rows (pw_touch_a); stagger: start-up phase shift of the workgroups
     float out_scale;
     unsigned a_bytes, a1_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
+    unsigned* trace; int trace_blk, trace_wave;     // EXPERIMENT (-DMVLDM_PW_TRACE, tools/pw_trace.py): s_memtime stamps of one wave
 };
+
+#ifdef MVLDM_PW_TRACE
+// stamp k of the traced wave: low 32 bits of the shader clock into the spare LDS behind the bias slab (192 stamps), dumped at the end
+#define PW_STAMP() if (tr_on && tr_n < 190) { reinterpret_cast<unsigned*>(smem + G::SLAB + 1280)[tr_n++] = (unsigned)__builtin_readcyclecounter(); }
+#else
+#define PW_STAMP()
+#endif
 
 #ifdef MVLDM_EXPERIMENTS
 static const int kPwFake = knob_int("MVLDM_PW_FAKE", 0);   // 1: no A traffic, 2: no W traffic, 4: no stores
@@ -137,6 +145,27 @@ __device__ __forceinline__ void pw_issue_w(const LinPWParams& p, char* smem, int
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(stage + (wave + PW_NW * it) * 1024), 16, off,
                                                  soff + it * 128 * p.K, 0, 0);
     }
+}
+
+// L2 PREFETCH of the activation rows of a K-step a few steps ahead of the ring (round 6).  The ring lives in LDS: a step's pieces are
+// requested ONE step before they are needed, and activation rows that come from HBM / the Infinity Cache take longer than that under
+// load (tools/gemm_diag.sh: fabric read latency ~ 800 clocks on average, 27 % of the L2 requests miss).  A "touch" is a 4-byte LDS-DMA
+// load per 64-byte half line into a dummy LDS word: it costs one VMEM instruction per wave and step, no register, and pulls the line
+// into the XCD's L2, where the ring's request two steps later finds it.  VMEM returns in order, so the touch is issued at the TOP of a
+// step: the step's counted wait (for the pieces issued one step earlier, which are OLDER) leaves it in flight -- vmcnt(1) -- and it has
+// 1.75 steps to return before the next wait needs it gone.
+template <int TN>
+__device__ __forceinline__ void pw_touch_a(const LinPWParams& p, char* smem, int wave, int lane, int tm, int ks, bool valid) {
+    using G = PwGeo<TN>;
+    const bool second = ks >= p.kt0;
+    const void* abase = second ? p.a1 : p.a;
+    const unsigned abytes = second ? p.a1_bytes : p.a_bytes;
+    const int c = second ? p.c1 : p.c0;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(abase), 0, abytes, 0x00020000);
+    const int m = tm * PW_BM + wave * 32 + (lane >> 1);
+    const unsigned off = (valid && m < p.M) ? ((unsigned)m * (unsigned)c * 2u + (unsigned)(lane & 1) * 64u) : kPwOob;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(smem + G::SLAB + 1792), 4, off,
+                                             (second ? ks - p.kt0 : ks) * 128, 0, 0);
 }
 
 template <int TN>
@@ -288,6 +317,10 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
     int ks_i = 1;                                // issue side: K-step of the newest ring step in flight
     const int kT = p.k_steps;
 
+    if (p.stagger) {     // (experiment: workgroups of an XCD start a fraction of a K-step apart, so that their ring bursts do not coincide)
+        const int ph = lid & 3;
+        for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     // ---- prologue: steps 0 and 1 of the first tile (the whole ring), its bias slab ----
     {
         pw_offsets<TN>(p, true, cur.tm, cur.tn, wave, lane, ad);
@@ -301,6 +334,10 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
         if (4 * tid < G::BN) *reinterpret_cast<u32x4*>(smem + G::SLAB + tid * 16) = b;
     }
     int rs = 0;                                  // ring slot the current step reads
+#ifdef MVLDM_PW_TRACE
+    const bool tr_on = p.trace && (int)blockIdx.x == p.trace_blk && wave == p.trace_wave;
+    int tr_n = 0;
+#endif
 
 // One K-step (64 of K) = four sub-steps of 16.  A sub-step runs the 2 * TN MFMAs of its fragments column by column (two row blocks per
 // W fragment) and, between the columns, fetches the NEXT sub-step's fragments one column ahead -- a W fragment's registers are free as
@@ -334,20 +371,34 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     }
-#define PW_STEP(LAST_, WAIT_)                                                                                     \
+#define PW_STEP(LAST_, WAIT_, TOUCH_)                                                                             \
     {                                                                                                             \
+        PW_STAMP()                                                                                                \
+        if ((TOUCH_) && p.touch) {                                                                                \
+            /* (ONE call with scalar-selected arguments: two call sites merged into a waterfall loop over the descriptor) */ \
+            const int kt_ = ks_t + PW_TOUCH_AHEAD;                                                                \
+            const bool own_ = kt_ < kT;                                                                           \
+            pw_touch_a<TN>(p, smem, wave, lane, __builtin_amdgcn_readfirstlane(own_ ? cur.tm : nxt.tm),           \
+                           __builtin_amdgcn_readfirstlane(own_ ? kt_ : kt_ - kT), own_ || nxt.valid);             \
+        }                                                                                                         \
         PW_SUB(fa0, fw0, fa1, fw1, true, rs, 1, false)                                                            \
         PW_SUB(fa1, fw1, fa0, fw0, true, rs, 2, false)                                                            \
         PW_SUB(fa0, fw0, fa1, fw1, true, rs, 3, false)                                                            \
-        __builtin_amdgcn_s_waitcnt(WAIT_);                                                                        \
+        PW_STAMP()                                                                                                \
+        if ((TOUCH_) && p.touch) __builtin_amdgcn_s_waitcnt(kWaitStep1);                                          \
+        else __builtin_amdgcn_s_waitcnt(WAIT_);                                                                   \
+        PW_STAMP()                                                                                                \
         __builtin_amdgcn_s_barrier();                                                                             \
+        PW_STAMP()                                                                                                \
         PW_SUB(fa1, fw1, fa0, fw0, !(LAST_), rs ^ 1, 0, true)                                                     \
         rs ^= 1;                                                                                                  \
     }
     Frag fa0[2], fw0[TN], fa1[2], fw1[TN];
     constexpr int kWaitLds = 0xC07F;                             // lgkmcnt(0) only
     constexpr int kWaitFirst = pw_wait(4 * NOUT) & ~0x0F00;      // step 1 of the tile has landed: everything but the previous epilogue's 4 * NOUT stores
-    constexpr int kWaitStep = pw_wait(0) & ~0x0F00;              // vmcnt(0) lgkmcnt(0): step g+1 has landed (and every older store)
+    constexpr int kWaitStepT = pw_wait(0) & ~0x0F00;             // vmcnt(0) lgkmcnt(0): step g+1 has landed (and every older store)
+    constexpr int kWaitStep1 = pw_wait(1) & ~0x0F00;             // ... vmcnt(1): the step's own touch (younger) may be in flight
+    constexpr int PW_TOUCH_AHEAD = 4;                            // the ring requests step g+2 in step g: the touch runs two steps ahead of it
 
     for (; cur.valid; cur = nxt, nxt.set(p, nxt.r + 1, lid, m_lo, m_cnt)) {
         // ---- the tile starts from its bias (slab written in the prologue / the previous epilogue, published by this barrier).  Steps 0
@@ -371,9 +422,10 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fw0[j] = pw_frag<T>(st0 + w_off + j * 4096);
         }
-        PW_STEP(false, kWaitFirst)
+        { const int ks_t = 0; PW_STEP(false, kWaitFirst, false) }
+        // (the middle steps carry one touch each: issued at the top of the step, i.e. younger than the pieces the step waits for)
 #pragma unroll 1
-        for (int ks = 1; ks < kT - 1; ++ks) PW_STEP(false, kWaitStep)
+        for (int ks_t = 1; ks_t < kT - 1; ++ks_t) PW_STEP(false, kWaitStepT, true)
         // Last step: nothing of the next tile is read before the epilogue.  The next tile's bias is requested here (inline asm: consumed
         // in the epilogue behind a counted wait that leaves the ring pieces this step issues in flight -- the epilogue does not drain the ring)
         u32x4 bnext;
@@ -383,8 +435,9 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
             const unsigned boff = pw_bias_off<TN>(p, GEGLU, nxt.valid, nxt.tn, tid);
             asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bnext) : "v"(boff), "s"(rbias));
         }
-        PW_STEP(true, kWaitLds)
+        { const int ks_t = 0; PW_STEP(true, kWaitLds, false) }
         // ---- epilogue: straight from the accumulators (header) ----
+        PW_STAMP()
         {
             const int col0 = GEGLU ? (cur.tn * G::BN + wn * 32 * TN) >> 1 : cur.tn * G::BN + wn * 32 * TN;
             unsigned row_dst[2], row_res[2];
@@ -465,6 +518,13 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
     }
     // (the ring pieces issued past the last tile are out of range: zeros into slots nobody reads; nothing to drain but the stores,
     //  which the end of the program waits for)
+#ifdef MVLDM_PW_TRACE
+    if (tr_on) {
+        PW_STAMP()
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 192; i += 64) p.trace[i] = i < tr_n ? reinterpret_cast<const unsigned*>(smem + G::SLAB + 1280)[i] : 0u;
+    }
+#endif
 #undef PW_SUB
 #undef PW_STEP
 }
@@ -538,6 +598,16 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     // write-back stores unless forced (header): MVLDM_STREAM_STORES=1 is the A/B knob
     static const int kNt = knob_int("MVLDM_STREAM_STORES", 0);
     p.nt_store = kNt == 1;
+    p.touch = (d.tile >> 13) & 1;                 // bit 13 of `tile`: the L2 prefetch (a tuner candidate: +4 % on some shapes, -9 % on others)
+    p.trace = nullptr; p.trace_blk = 0; p.trace_wave = 0;
+#ifdef MVLDM_PW_TRACE
+    if (const char* tp = getenv("MVLDM_PW_TRACE_PTR")) {
+        p.trace = reinterpret_cast<unsigned*>(strtoull(tp, nullptr, 16));
+        p.trace_blk = getenv("MVLDM_PW_TRACE_BLK") ? atoi(getenv("MVLDM_PW_TRACE_BLK")) : 8;
+        p.trace_wave = getenv("MVLDM_PW_TRACE_WAVE") ? atoi(getenv("MVLDM_PW_TRACE_WAVE")) : 0;
+    }
+#endif
+    p.stagger = (d.tile >> 14) & 3;               // bits 14-15: EXPERIMENT, phase shift of the workgroups' step cadence
     if (kPwFake & 1) p.a_bytes = p.a1_bytes = 0;
     if (kPwFake & 2) p.w_bytes = 0;
     if (kPwFake & 4) p.dst_bytes = 0;
