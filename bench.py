@@ -200,6 +200,7 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
         return [tr.training_step(batch, **ch) for _ in range(acc)]
     for _ in range(args.warmup):
         opt_step()
+    tr.opt.account_comm = True              # (timing events around the collective waits: off in a production trainer)
     tr.opt.comm_stats()                     # (reset the communication accounting: the timed steps only)
     barrier()
     t0 = time.perf_counter()
@@ -414,7 +415,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--op-table", default=None, help="write the per-op profile (JSON) here")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the b in {1, 4, 16} latency lines (and the 128-scene line)")
-    ap.add_argument("--no-large-batch", action="store_true", help="skip the 128-scene throughput line")
+    ap.add_argument("--no-large-batch", action="store_true", help="(default since round 6: the 128-scene line is opt-in, --large-batch)")
+    ap.add_argument("--large-batch", action="store_true", help="add the 128-scene throughput line (`large_batch`; ~40 s of wall clock)")
     ap.add_argument("--no-parity", action="store_true", help="skip the 50-step f32-vs-bench-dtype drift measurement")
     ap.add_argument("--no-train-line", action="store_true", help="skip the short training-step measurement appended to the sampling line")
     ap.add_argument("--no-full-walk", action="store_true", help="skip the 2-sample run without the exact sharing (`exact_sharing.full_walk`)")
@@ -508,8 +510,15 @@ def main():
     batch = synthetic_batch(b, v_c, v_t, args.res, 1234, dev, scene_ids=owned)
 
     if args.unet_pass_only:
+        # ONE eager UNet + DDIM pass between two sentinel launches (a kernel no other part of the process uses: `bessel_j0`):
+        # tools/profile_tables.py cuts the rocprofv3 trace there, so that the committed per-kernel table holds the pass and nothing else
+        # (no weight initialisation, no VAE encode, no plan recording)
         st = pipe.prepare(batch)
+        torch.cuda.synchronize()
+        mark = torch.zeros(64, device=dev)
+        torch.special.bessel_j0(mark)
         st["plan"].run()
+        torch.special.bessel_j0(mark)
         torch.cuda.synchronize()
         return
 
@@ -667,7 +676,7 @@ def main():
             small[f"b{sb}"] = {"views_per_s": round(sb * v_t / dt_s, 3), "sample_ms": round(dt_s * 1e3, 2),
                                "ddim_step_ms": round(step, 4), "two_roof": tr}
         out["small_batch"] = small
-        if b == 64 and args.dtype != "f32" and not getattr(args, "no_large_batch", False):
+        if b == 64 and args.dtype != "f32" and getattr(args, "large_batch", False) and not getattr(args, "no_large_batch", False):
             # ---- and the other side of 64 scenes: the 288 GB of one GPU take more, and the tile quantisation of the deep levels eases off
             # (`value` stays at 64 scenes per GPU, the configuration of every earlier round's line)
             lb_ = 128
@@ -707,7 +716,7 @@ def main():
             # ---- the same workload in f16 -- the reference's own `16-mixed` arithmetic, the 16-bit type that meets the 1e-3
             # north-star tolerance (bf16 does not) -- timed here so that the tolerance-meeting precision has a number on the
             # same line, from the same process on the same box: whole `sample()`s incl. VAE encode + decode, like `value`
-            alt, alt_steps = torch.float16, 6
+            alt, alt_steps = torch.float16, 3       # (3 whole samples: the default line must finish inside ~400 s of wall clock)
             with mv_ldm_amd.compute_dtype(alt):
                 pipe.sample(batch)                                   # records + tunes the f16 plans (UNet and VAE)
                 torch.cuda.synchronize()
@@ -730,6 +739,12 @@ def main():
             out["f16_latent_rel_err_after_50_steps"] = out["alt_dtype"]["parity_rel_err"][f"f16_vs_f32_latents_after_{args.ddim_steps}_steps"]
             out["bf16_latent_rel_err_after_50_steps"] = round(err, 5)
             out["north_star_latent_tolerance"] = 1e-3
+            # round 6: the tolerance-meeting headline, spelled out.  bf16 (the dtype BASELINE.json's configs[1] names, `value`) drifts ~6e-3
+            # over 50 steps; the priced alternative -- an fp32 residual trunk under bf16 MFMA operands -- still leaves > 1e-3 from the
+            # 16-bit WEIGHTS alone (profiles/r06_bf16_trunk_ablation.json), so f16, the reference's own `16-mixed` arithmetic, is the
+            # 16-bit type that satisfies the north star's 1e-3
+            out["value_within_tolerance"] = {"dtype": "f16", "value": out["f16_value"], "unit": "views/s",
+                                             "latent_rel_err_after_50_steps": out["f16_latent_rel_err_after_50_steps"], "tolerance": 1e-3}
     out["exact_sharing"] = {
         "enabled": os.environ.get("MVLDM_CFG_SHARE", "1") != "0",
         "what": "algebraically exact reuse inside one sample(): the unconditional CFG pass re-submits the conditional pass's target views, so "
@@ -747,12 +762,12 @@ def main():
             pipe.sample(batch)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(6):
+            for _ in range(3):
                 img_f, _ = pipe.sample(batch)
             torch.cuda.synchronize()
-            fw_s = (time.perf_counter() - t0) / 6
+            fw_s = (time.perf_counter() - t0) / 3
             assert torch.isfinite(img_f).all()
-            out["exact_sharing"]["full_walk"] = {"value": round(b * v_t / fw_s, 3), "unit": "views/s", "steps": 6, "warmup": 1,
+            out["exact_sharing"]["full_walk"] = {"value": round(b * v_t / fw_s, 3), "unit": "views/s", "steps": 3, "warmup": 1,
                                                  "ms_per_step": round(1e3 * fw_s, 3)}
         finally:
             for k, v in saved.items():

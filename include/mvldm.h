@@ -27,8 +27,9 @@ extern "C" {
 /* 3 (round 3): + mvldm_gather_rows, mvldm_ddpm_cfg_step, mvldm_ema_update; plan ops MVLDM_OP_PAR_BEGIN / _NEXT / _END and
  * MVLDM_OP_GATHER_ROWS / MVLDM_OP_ATTN_MERGE; bits 8-9 of mvldm_wgrad_desc.accumulate select the weight-gradient kernel form.  Everything of version 2 is
  * unchanged (additive).
- * 4 (round 5): + mvldm_pack_skinny and tile 15 / k_order 2 of mvldm_igemm_fwd (the skinny-M weight-streaming GEMM); additive over 3. */
-#define MVLDM_ABI_VERSION 4
+ * 4 (round 5): + mvldm_pack_skinny and tile 15 / k_order 2 of mvldm_igemm_fwd (the skinny-M weight-streaming GEMM); additive over 3.
+ * 5 (round 6): + tile 19 of mvldm_igemm_fwd (register-staged Linear), tile 13's bit 13, mvldm_build_flags; additive over 4. */
+#define MVLDM_ABI_VERSION 5
 
 typedef void* mvldm_stream_t; /* hipStream_t */
 
@@ -42,6 +43,8 @@ enum { MVLDM_EPI_NONE = 0, MVLDM_EPI_SILU = 1, MVLDM_EPI_GEGLU = 2, MVLDM_EPI_GE
 enum { MVLDM_ELT_COPY = 0, MVLDM_ELT_SILU = 1, MVLDM_ELT_GELU = 2 };
 
 int mvldm_abi_version(void);
+/* bit 0: the library was compiled with -DMVLDM_EXPERIMENTS (its kernels read the A/B environment knobs of tools/; the product build reads none) */
+int mvldm_build_flags(void);
 const char* mvldm_last_error(void);
 /* cu_count / hbm_bytes of the current device; arch receives e.g. "gfx950" */
 int mvldm_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);

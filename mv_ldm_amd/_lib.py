@@ -11,7 +11,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libmvldm_hip.so"
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_SILU, EPI_GEGLU, EPI_GELU = 0, 1, 2, 3
 RAYS_RAW, RAYS_POSITIONAL, RAYS_SRT = 0, 1, 2
@@ -182,6 +182,7 @@ class Op(C.Structure):
 # name -> (restype, argtypes); mirrors include/mvldm.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
     "mvldm_abi_version": (C.c_int, []),
+    "mvldm_build_flags": (C.c_int, []),
     "mvldm_last_error": (C.c_char_p, []),
     "mvldm_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(sz), C.c_char_p, C.c_int]),
     "mvldm_igemm_fwd": (C.c_int, [C.POINTER(IgemmDesc), vp]),
@@ -238,6 +239,13 @@ class MvldmError(RuntimeError):
     pass
 
 
+_EXPERIMENT_KNOBS = ("MVLDM_ADAMW_NT", "MVLDM_ATTN_QB", "MVLDM_ATTN_WIDE_VALU", "MVLDM_GN_NTHR", "MVLDM_GN_SPAN", "MVLDM_GN_TWOPASS", "MVLDM_GN_WIDE",
+                     "MVLDM_IGEMM_FAKE", "MVLDM_IGEMM_GROUP", "MVLDM_IGEMM_NOSTAGE", "MVLDM_IGEMM_PX", "MVLDM_IGEMM_SYNC", "MVLDM_IGEMM_TARGET",
+                     "MVLDM_LPP_CPT", "MVLDM_LPP_FAKE", "MVLDM_PLAN_SERIAL", "MVLDM_PW_FAKE", "MVLDM_PW_GM", "MVLDM_PW_TN", "MVLDM_RS_FAKE", "MVLDM_SK_FAKE",
+                     "MVLDM_STREAM_STORES", "MVLDM_WGRAD_DIRECT", "MVLDM_WGRAD_TARGET", "MVLDM_WGRAD_WIDE", "MVLDM_WGRAD_WIDE_BP",
+                     "MVLDM_WGRAD_WIDE_TARGET", "MVLDM_WGRAD_XCD", "MVLDM_WS_FAKE")
+
+
 def load(required: bool = True):
     """dlopen the in-tree shared library and attach prototypes.  No fallback: raises if absent."""
     global _lib
@@ -254,6 +262,15 @@ def load(required: bool = True):
         fn.restype, fn.argtypes = res, args
     if lib.mvldm_abi_version() != ABI_VERSION:
         raise MvldmError("libmvldm_hip.so ABI version mismatch")
+    # The product library reads NO environment variable (csrc/common.h knob_int): a tool that sets one of the kernel-level A/B knobs
+    # against it would compare a path with itself and pass vacuously -- refuse instead.  Experiment builds report
+    # bit 0 of mvldm_build_flags; the single-file experiment libraries of tools/*_probe.sh are recognised by their file name.
+    if not (lib.mvldm_build_flags() & 1) and "_exp" not in LIB_PATH.name:
+        import os
+        stale = sorted(k for k in _EXPERIMENT_KNOBS if k in os.environ)
+        if stale:
+            raise MvldmError(f"{', '.join(stale)} set, but {LIB_PATH.name} was built without -DMVLDM_EXPERIMENTS and ignores it: build an "
+                             "experiment library (MVLDM_EXPERIMENTS=1 python -m mv_ldm_amd._build --force, or tools/*_probe.sh + --lib) or unset it")
     _lib = lib
     return lib
 

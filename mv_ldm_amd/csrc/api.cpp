@@ -18,6 +18,13 @@ int set_error(int code, const char* fmt, ...) {
 
 extern "C" int mvldm_abi_version(void) { return MVLDM_ABI_VERSION; }
 extern "C" const char* mvldm_last_error(void) { return mvldm::g_err; }
+extern "C" int mvldm_build_flags(void) {
+#ifdef MVLDM_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int mvldm_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len) {
     int dev = 0;

@@ -306,8 +306,8 @@ __device__ __forceinline__ void epi_rows(const IgemmParams& p, const float* st, 
                 const f32x4 gb = *reinterpret_cast<const f32x4*>(st + row * PITCH + voff + 36);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] *= gelu_erf_fast(ga[e] + bg[e]);
-                    v[4 + e] *= gelu_erf_fast(gb[e] + bg[4 + e]);
+                    v[e] *= gelu_erf_16(ga[e] + bg[e]);
+                    v[4 + e] *= gelu_erf_16(gb[e] + bg[4 + e]);
                 }
             } else {
                 if (rb_on && rb_pre) {

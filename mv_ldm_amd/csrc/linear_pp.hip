@@ -143,7 +143,7 @@ template <typename T> __device__ __forceinline__ typename LpMma<T>::Frag lp_frag
 #ifdef MVLDM_EXPERIMENTS_NOGELU
 #define LP_GELU(x) (x)
 #else
-#define LP_GELU(x) gelu_erf_fast(x)
+#define LP_GELU(x) gelu_erf_16(x)
 #endif
 
 // epilogue-side coordinates of the finished tile, per lane (lane & 31 = row inside a 32-row block)
@@ -191,7 +191,7 @@ __device__ __forceinline__ void lp_epi_compute(const LinPPParams& p, const f32x1
         for (int k = 0; k < 16; ++k) c[k] = silu_f(c[k]);
     } else if constexpr (EPI == MVLDM_EPI_GELU) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) c[k] = gelu_erf_fast(c[k]);
+        for (int k = 0; k < 16; ++k) c[k] = gelu_erf_16(c[k]);
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {

@@ -41,7 +41,7 @@ struct LinPWParams {
     int M, K, c0, c1, kt0, n_out, n_pad, n_dst, dst_ld, k_steps;    // K = c0 + c1; K-steps [0, kt0) come from `a`, the rest from `a1`
     int tiles_m, tiles_n, m_per;       // m_per: 256-row blocks per XCD
     int gm, gn, nbn, wgx;              // an XCD's wgx workgroups walk its tiles in gm x gn blocks, column chunks (nbn of them) fastest
-    int nt_store, touch, stagger;      // touch: L2 prefetch of the activation rows (pw_touch_a); stagger: start-up phase shift of the workgroups
+    int nt_store, touch;               // touch: L2 prefetch of the activation rows (pw_touch_a)
     float out_scale;
     unsigned a_bytes, a1_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
     unsigned* trace; int trace_blk, trace_wave;     // EXPERIMENT (-DMVLDM_PW_TRACE, tools/pw_trace.py): s_memtime stamps of one wave
@@ -62,7 +62,7 @@ static constexpr int kPwFake = 0;
 #ifdef MVLDM_EXPERIMENTS_NOGELU
 #define PW_GELU(x) (x)
 #else
-#define PW_GELU(x) gelu_erf_fast(x)
+#define PW_GELU(x) gelu_erf_16(x)
 #endif
 
 constexpr unsigned kPwOob = 0xFFFFFFF0u;
@@ -230,6 +230,45 @@ template <typename T> __device__ __forceinline__ typename PwMma<T>::Frag pw_frag
     return *reinterpret_cast<const typename PwMma<T>::Frag*>(p);
 }
 
+// ---- whole-line epilogue traffic (round 6) ---------------------------------------------------------------------------------------------
+// The transposed product leaves a lane with ONE row and, per 32-column block, two 16-byte chunks of it; the two lanes of a row (hi = 0 / 1)
+// interleave, so a store instruction writes 32 rows x 32 contiguous bytes -- four requests per 128-byte line, and tools/pw_trace.py showed
+// the XCD's L2 taking a tile's 164 KB of stores (and as many residual bytes) at REQUEST rate: 15 - 28 k cycles per tile next to 3.7 k per
+// K-step.  For a PAIR of blocks (j even, j + 1) a lane holds chunks C0..C3 = chunk indices hi, 2 + hi, 4 + hi, 6 + hi of its row's 128-byte
+// segment.  The four lanes of a quad (four consecutive rows, same hi) TRANSPOSE the 4 x 4 (chunk, lane) matrix -- lane k ends with chunk
+// k of rows 0..3, D_t(k) = C_k(lane t) -- so that store instruction t writes, per quad, chunks 2k + hi of row t: with both halves 8
+// consecutive chunks = one whole line per row, 8 lines per instruction.  Two butterfly stages by DPP quad permutes (lane ^ 1, lane ^ 2), one
+// select per register each.  The transpose is its own inverse: residual chunks loaded with the same line-shaped addressing go through it
+// once to reach the accumulator layout.
+template <int CTRL> __device__ __forceinline__ u32x4 pw_qperm(const u32x4& v) {
+    u32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[c], CTRL, 0xF, 0xF, true);
+    return r;
+}
+__device__ __forceinline__ u32x4 pw_sel(bool take_a, const u32x4& a, const u32x4& b) {
+    u32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = take_a ? a[c] : b[c];
+    return r;
+}
+__device__ __forceinline__ void pw_quad_transpose(u32x4& c0, u32x4& c1, u32x4& c2, u32x4& c3, bool odd, bool upper) {
+    constexpr int X1 = 0xB1, X2 = 0x4E;        // quad_perm [1,0,3,2] / [2,3,0,1]
+    const u32x4 x0 = pw_sel(odd, pw_qperm<X1>(c1), c0), x1 = pw_sel(odd, c1, pw_qperm<X1>(c0));
+    const u32x4 x2 = pw_sel(odd, pw_qperm<X1>(c3), c2), x3 = pw_sel(odd, c3, pw_qperm<X1>(c2));
+    c0 = pw_sel(upper, pw_qperm<X2>(x2), x0);
+    c2 = pw_sel(upper, x2, pw_qperm<X2>(x0));
+    c1 = pw_sel(upper, pw_qperm<X2>(x3), x1);
+    c3 = pw_sel(upper, x3, pw_qperm<X2>(x1));
+}
+// byte offset (row-major, `ld` elements per row) at which lane (l31, hi) stores / loads transposed chunk t = 2 (j & 1) + half of the block
+// pair (j & ~1, j | 1) of row block i: row (quad's first row) + t, chunk 2 (l31 & 3) + hi of the pair's 128-byte segment
+__device__ __forceinline__ unsigned pw_line_off(int M, int tm, int wm, int i, int j, int half, int l31, int hi, int col0, int ld, int n_dst) {
+    const int t = 2 * (j & 1) + half, k = l31 & 3;
+    const int m = tm * PW_BM + wm * 64 + i * 32 + (l31 & ~3) + t;
+    const int col = col0 + 32 * (j & ~1) + 8 * (2 * k + hi);
+    return (m < M && col < n_dst) ? ((unsigned)m * (unsigned)ld + (unsigned)col) * 2u : kPwOob;
+}
 __device__ __forceinline__ unsigned pw_off(unsigned row, int col, int n_dst) {
     return (row != kPwRowNone && col < n_dst) ? row + (unsigned)col * 2u : kPwOob;
 }
@@ -317,10 +356,6 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
     int ks_i = 1;                                // issue side: K-step of the newest ring step in flight
     const int kT = p.k_steps;
 
-    if (p.stagger) {     // (experiment: workgroups of an XCD start a fraction of a K-step apart, so that their ring bursts do not coincide)
-        const int ph = lid & 3;
-        for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     // ---- prologue: steps 0 and 1 of the first tile (the whole ring), its bias slab ----
     {
         pw_offsets<TN>(p, true, cur.tm, cur.tn, wave, lane, ad);
@@ -440,6 +475,7 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
         PW_STAMP()
         {
             const int col0 = GEGLU ? (cur.tn * G::BN + wn * 32 * TN) >> 1 : cur.tn * G::BN + wn * 32 * TN;
+            const bool q_odd = (l31 & 1) != 0, q_upper = (l31 & 2) != 0;      // this lane's place in its quad (pw_quad_transpose)
             unsigned row_dst[2], row_res[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -457,10 +493,17 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
                 u32x4 rres;
                 rres[0] = (unsigned)(uintptr_t)p.residual; rres[1] = (unsigned)((uintptr_t)p.residual >> 32) & 0xFFFFu; rres[2] = p.res_bytes; rres[3] = 0x00020000u;
                 u32x4 r[NB][2];
+// (a block of a PAIR is loaded line-shaped -- pw_line_off -- and transposed into the accumulator layout when its partner has landed; the odd
+//  last block of a TN = 5 wave tile keeps the 32-byte form)
+#define PW_RES_OFFS(b_)                                                                                                         \
+        const bool pair_ = (((b_) % TN) | 1) < TN;                                                                              \
+        const unsigned o0_ = pair_ ? pw_line_off(p.M, cur.tm, wm, (b_) / TN, (b_) % TN, 0, l31, hi, col0, p.n_dst, p.n_dst)     \
+                                   : pw_off(row_res[(b_) / TN], col0 + 32 * ((b_) % TN) + 8 * hi, p.n_dst);                     \
+        const unsigned o1_ = pair_ ? pw_line_off(p.M, cur.tm, wm, (b_) / TN, (b_) % TN, 1, l31, hi, col0, p.n_dst, p.n_dst)     \
+                                   : pw_off(row_res[(b_) / TN], col0 + 32 * ((b_) % TN) + 16 + 8 * hi, p.n_dst);
 #define PW_RES_ISSUE(b_)                                                                                                        \
     if constexpr ((b_) < NB) {                                                                                                  \
-        const unsigned o0_ = pw_off(row_res[(b_) / TN], col0 + 32 * ((b_) % TN) + 8 * hi, p.n_dst);                             \
-        const unsigned o1_ = pw_off(row_res[(b_) / TN], col0 + 32 * ((b_) % TN) + 16 + 8 * hi, p.n_dst);                        \
+        PW_RES_OFFS(b_)                                                                                                         \
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen"             \
                      : "=&v"(r[(b_) < NB ? (b_) : 0][0]), "=&v"(r[(b_) < NB ? (b_) : 0][1]) : "v"(o0_), "v"(o1_), "s"(rres));   \
     }
@@ -474,9 +517,22 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
         } else {                                                                                                                \
             asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[(b_) < NB ? (b_) : 0][0]), "+v"(r[(b_) < NB ? (b_) : 0][1]) : "n"(2 * left_)); \
         }                                                                                                                       \
-        float c_[16];                                                                                                           \
-        _Pragma("unroll") for (int k = 0; k < 16; ++k) c_[k] = acc[i_][j_][k];                                                  \
-        pw_pack<T, true>(c_, p.out_scale, r[(b_) < NB ? (b_) : 0], out[i_][j_]);                                                \
+        constexpr bool paired_ = (j_ | 1) < TN;                                                                                 \
+        if constexpr (!paired_) {                                                                                               \
+            float c_[16];                                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) c_[k] = acc[i_][j_][k];                                              \
+            pw_pack<T, true>(c_, p.out_scale, r[(b_) < NB ? (b_) : 0], out[i_][j_]);                                            \
+        } else if constexpr ((j_ & 1) == 1) {                                                                                   \
+            /* the pair (b - 1, b) has landed: residual -> accumulator layout, both blocks packed, outputs -> line layout */    \
+            constexpr int bp_ = (b_) > 0 ? (b_) - 1 : 0;                                                                        \
+            pw_quad_transpose(r[bp_][0], r[bp_][1], r[(b_) < NB ? (b_) : 0][0], r[(b_) < NB ? (b_) : 0][1], q_odd, q_upper);    \
+            float c_[16];                                                                                                       \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) c_[k] = acc[i_][j_ - 1][k];                                          \
+            pw_pack<T, true>(c_, p.out_scale, r[bp_], out[i_][j_ - 1]);                                                         \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) c_[k] = acc[i_][j_][k];                                              \
+            pw_pack<T, true>(c_, p.out_scale, r[(b_) < NB ? (b_) : 0], out[i_][j_]);                                            \
+            pw_quad_transpose(out[i_][j_ - 1][0], out[i_][j_ - 1][1], out[i_][j_][0], out[i_][j_][1], q_odd, q_upper);          \
+        }                                                                                                                       \
         PW_RES_ISSUE((b_) + PW_D)                                                                                               \
     }
                 constexpr int PW_D = 4;
@@ -505,6 +561,7 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
                         }
                         const u32x4 none[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
                         pw_pack<T, false>(c, p.out_scale, none, out[i][j]);
+                        if ((j & 1) == 1) pw_quad_transpose(out[i][j - 1][0], out[i][j - 1][1], out[i][j][0], out[i][j][1], q_odd, q_upper);
                     }
             }
             // stores last: no load is waited for while they are in flight (header)
@@ -512,8 +569,12 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NOUT; ++j)
-                    pw_store2<NT>(rdst, out[i][j][0], pw_off(row_dst[i], col0 + 32 * j + 8 * hi, p.n_dst), out[i][j][1],
-                                  pw_off(row_dst[i], col0 + 32 * j + 16 + 8 * hi, p.n_dst));
+                    if ((j | 1) < NOUT)      // a pair: whole 128-byte row segments (the chunks were transposed inside the quad)
+                        pw_store2<NT>(rdst, out[i][j][0], pw_line_off(p.M, cur.tm, wm, i, j, 0, l31, hi, col0, p.dst_ld, p.n_dst), out[i][j][1],
+                                      pw_line_off(p.M, cur.tm, wm, i, j, 1, l31, hi, col0, p.dst_ld, p.n_dst));
+                    else
+                        pw_store2<NT>(rdst, out[i][j][0], pw_off(row_dst[i], col0 + 32 * j + 8 * hi, p.n_dst), out[i][j][1],
+                                      pw_off(row_dst[i], col0 + 32 * j + 16 + 8 * hi, p.n_dst));
         }
     }
     // (the ring pieces issued past the last tile are out of range: zeros into slots nobody reads; nothing to drain but the stores,
@@ -607,7 +668,6 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
         p.trace_wave = getenv("MVLDM_PW_TRACE_WAVE") ? atoi(getenv("MVLDM_PW_TRACE_WAVE")) : 0;
     }
 #endif
-    p.stagger = (d.tile >> 14) & 3;               // bits 14-15: EXPERIMENT, phase shift of the workgroups' step cadence
     if (kPwFake & 1) p.a_bytes = p.a1_bytes = 0;
     if (kPwFake & 2) p.w_bytes = 0;
     if (kPwFake & 4) p.dst_bytes = 0;

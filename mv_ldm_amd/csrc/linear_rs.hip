@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void linear_rs_kernel(const LinRSParams p) {
                             const f32x4 bg = *reinterpret_cast<const f32x4*>(slab + 32 * (2 * j + 1) + 16 * (a >> 1) + 4 * (a & 1));
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                c[4 * a + e] = (acc[i][2 * j][4 * a + e] + bv[e]) * gelu_erf_fast(acc[i][2 * j + 1][4 * a + e] + bg[e]);
+                                c[4 * a + e] = (acc[i][2 * j][4 * a + e] + bv[e]) * gelu_erf_16(acc[i][2 * j + 1][4 * a + e] + bg[e]);
                         }
                     } else {
 #pragma unroll

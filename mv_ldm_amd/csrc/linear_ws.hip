@@ -41,7 +41,7 @@ static constexpr int kWsFake = 0;
 #ifdef MVLDM_EXPERIMENTS_NOGELU
 #define WS_GELU(x) (x)
 #else
-#define WS_GELU(x) gelu_erf_fast(x)
+#define WS_GELU(x) gelu_erf_16(x)
 #endif
 
 constexpr unsigned kWsOob = 0xFFFFFFF0u;

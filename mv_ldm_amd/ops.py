@@ -69,6 +69,7 @@ class PackedWeight:
     geglu: bool = False
     k_order: int = 0    # 1: K stored as (channel block, tap, channel) -- needs every source's channels % BK == 0
     _skinny: Optional[torch.Tensor] = None
+    _skinny_pinned: bool = False     # an op of some plan points at the fragment-order copy: it stays with the pack (drop_skinny is a no-op)
 
     def can_skinny(self) -> bool:
         """does igemm tile 15 (csrc/skinny.hip) read this weight?  16-bit block-major packs whose channel count is a multiple of 64"""
@@ -86,7 +87,8 @@ class PackedWeight:
         return self._skinny
 
     def drop_skinny(self):
-        self._skinny = None
+        if not self._skinny_pinned:
+            self._skinny = None
 
 
 def block_k(dtype: torch.dtype) -> int:

@@ -401,6 +401,16 @@ def install_fused_sampler(wrapper, *, num_inference_steps: Optional[int] = None)
     Returns the pipeline object that now backs `sample` (its recorded plans live there; `wrapper._mvldm_pipeline`)."""
     mc = wrapper.model_cfg
 
+    def _rays() -> RayEncodingCfg:
+        # the wrapper's own ray-encoding switches (diffusion_wrapper.py:98-127 builds the encoders from them, :301-320 applies them)
+        re_ = getattr(mc, "ray_encodings", None)
+        d = RayEncodingCfg()
+        return RayEncodingCfg(use_ray_encoding=bool(getattr(mc, "use_ray_encoding", False)),
+                              srt_ray_encoding=bool(getattr(mc, "srt_ray_encoding", False)),
+                              use_plucker=bool(getattr(mc, "use_plucker", False)),
+                              num_origin_octaves=int(getattr(re_, "num_origin_octaves", d.num_origin_octaves)),
+                              num_direction_octaves=int(getattr(re_, "num_direction_octaves", d.num_direction_octaves)))
+
     def _denoiser():
         if getattr(mc, "use_ema_sampling", False) and getattr(wrapper, "ema", None) is not None:
             return getattr(wrapper.ema, "module", wrapper.ema)
@@ -410,12 +420,20 @@ def install_fused_sampler(wrapper, *, num_inference_steps: Optional[int] = None)
         raise TypeError("install_fused_sampler: wrapper.denoiser is not mv_ldm_amd.mvunet.MultiViewUNet -- register the HIP classes in the "
                         "reference's DENOISER / SCHEDULER / AUTOENCODERS registries first (INTEGRATION.md level A)")
     pipe = MVLDMPipeline(_denoiser(), wrapper.autoencoder, wrapper.scheduler,
-                         SamplerCfg(bool(mc.use_cfg), float(mc.cfg_scale), int(num_inference_steps or len(wrapper.scheduler.timesteps) or 50)))
+                         SamplerCfg(bool(mc.use_cfg), float(mc.cfg_scale), int(num_inference_steps or len(wrapper.scheduler.timesteps) or 50)),
+                         rays=_rays())
 
     def sample(batch):
         den = _denoiser()
         if den is not pipe.denoiser:                       # EMA switched on / off since the last call
             pipe.denoiser = den
+            pipe._plans.clear()
+        rays = _rays()
+        if rays != pipe.rays:                              # re-read like cfg_scale (a changed channel count fails in the constructor's check)
+            need = rays.denoiser_in_channels(den.out_channels)
+            if den.in_channels != need:
+                raise ValueError(f"install_fused_sampler: the ray encoding now needs {need} denoiser input channels, the denoiser has {den.in_channels}")
+            pipe.rays = rays
             pipe._plans.clear()
         cfg = (bool(mc.use_cfg), float(mc.cfg_scale))
         if cfg != (pipe.cfg.use_cfg, pipe.cfg.cfg_scale):

@@ -599,9 +599,9 @@ _TUNE_COLD = int(os.environ.get("MVLDM_TUNE_COLD", "9216"))
 _THRASH = []
 
 
-def _thrash():
-    if not _THRASH:
-        _THRASH.append(torch.empty(640 << 20, dtype=torch.uint8, device=torch.cuda.current_device()))      # > 2 x the 256 MB Infinity Cache
+def _thrash(device=None):
+    if not _THRASH or (device is not None and _THRASH[0].device != torch.device(device)):
+        _THRASH[:] = [torch.empty(640 << 20, dtype=torch.uint8, device=torch.cuda.current_device() if device is None else device)]   # > 2 x the 256 MB Infinity Cache
     return _THRASH[0]
 
 
@@ -617,6 +617,7 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
     stream = torch.cuda.current_stream().cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     timed = 0
+    tune_dev = next((t.device for pair in (srcs or {}).values() for t in pair if t is not None), None)      # the plan's device (cold-cache fill)
     if srcs:
         seen, gen = set(), None
         for pair in srcs.values():
@@ -638,7 +639,7 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
         small = rows < min_rows
         key = _igemm_signature(d) + (("sk",) if sk_pw is not None else ())
         best = _TUNE_CACHE.get(key)
-        if best is not None and (_unpack_choice(best)[0] & 63) not in (set(_TUNE_TILES) | set(_SMALL_TILES) | {17} | ({15} if sk_pw is not None else set())):
+        if best is not None and (_unpack_choice(best)[0] & 63) not in (set(_TUNE_TILES) | set(_SMALL_TILES) | {17, 19} | ({15} if sk_pw is not None else set())):
             best = None          # an entry of an older build / another candidate set (a tile this build no longer offers): time it again
         if best is None:
             trial = L.Op()
@@ -654,6 +655,9 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
             if not small and 17 not in _TUNE_TILES and not os.environ.get("MVLDM_TUNE_TILES") and d.ksize == 3 and d.stride == 1 \
                     and d.src1 is None and not d.upsample and d.w_in <= 24:
                 cands = cands + [(17, None)]     # the wide pixel-halo tile: one-source 3x3 convs on maps up to 24 wide (elsewhere it is tile 7)
+            if not small and d.ksize == 1 and not os.environ.get("MVLDM_TUNE_TILES"):
+                # round 6: the register-staged Linear (tile 19) and tile 13 with the L2 prefetch of its activation rows (bit 13)
+                cands = cands + [(19, None), (13 | (1 << 13), None)]
             if sk_pw is not None:            # tile 15 in every configuration the library accepts for this problem (others return an error)
                 cands = cands + [(15 | (c << 8), 1) for c in _SKINNY_CFGS]
                 sk_ptr = sk_pw.skinny().data_ptr()
@@ -669,7 +673,7 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
                     # its weights come from HBM; back-to-back trials would read them from the Infinity Cache and rank the tiles differently
                     t_sum = 0.0
                     for _ in range(n_it):
-                        _thrash().zero_()
+                        _thrash(tune_dev).zero_()
                         e0.record()
                         lib.mvldm_op_run(C.byref(trial), stream)
                         e1.record()
@@ -713,13 +717,15 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
             d.splitk = sk
         if (tile & 63) == 15:                # the fragment-order copy of the weight stays with the plan
             t = sk_pw.skinny()
+            sk_pw._skinny_pinned = True      # the op holds a raw pointer: the copy stays with the pack whoever else shares it
             d.weight, d.k_order = t.data_ptr(), 2
             if keep is not None:
                 keep.append(t)
         elif sk_pw is not None:
-            sk_pw.drop_skinny()              # not chosen: the copy made for the trials is not kept
+            sk_pw.drop_skinny()              # not chosen: the copy made for the trials is not kept (a no-op while another op points at it)
     if timed:
         save_tune_cache()
+        _THRASH.clear()                      # the 640 MB cold-cache fill is a tuning-time buffer: not kept past the plan that needed it
     return timed
 
 

@@ -954,6 +954,10 @@ class DistributedOptimizer:
         self.bytes_gathered = 0
         self._exposed = []            # (start event, end event) pairs around every wait for collectives on the compute stream
         self.bucket_events = {}       # bucket -> event recorded on the compute stream when its reduce was enqueued (last step)
+        # The timing events are an OPT-IN (bench.py --train and the tests set `account_comm = True`): a production run would otherwise
+        # create ~ (buckets + 4) events per optimizer step and keep the exposed-wait pairs until somebody called comm_stats() -- nobody
+        # does in a training loop.  The byte counters are plain integers and always on.
+        self.account_comm = False
 
     # ---- learning rate (LinearLR: factor after `step_count` scheduler steps) ----
     def lr(self) -> float:
@@ -971,7 +975,7 @@ class DistributedOptimizer:
         oa, ob = self.owned[k]
         g = self.flat.grad
         self.bytes_reduced += (b - a) * 4
-        if g.is_cuda:
+        if g.is_cuda and self.account_comm:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.bucket_events[k] = ev
@@ -981,7 +985,7 @@ class DistributedOptimizer:
             self._pending.append(dist.reduce_scatter_tensor(g[oa:ob], g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
-        timed = bool(self._pending) and self.flat.grad.is_cuda
+        timed = self.account_comm and bool(self._pending) and self.flat.grad.is_cuda
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1041,12 +1045,13 @@ class DistributedOptimizer:
                 n = (b - a) // self.world
                 dist.all_gather([p[a + r * n:a + (r + 1) * n] for r in range(self.world)], p[a + self.rank * n:a + (self.rank + 1) * n].clone(),
                                 group=self.group)
-        if works and p.is_cuda:
+        timed = self.account_comm and bool(works) and p.is_cuda
+        if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         for w in works:
             w.wait()
-        if works and p.is_cuda:
+        if timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             self._exposed.append((e0, e1))
@@ -1526,7 +1531,7 @@ class MVLDMTrainer:
             self.opt.reduce_bucket(k)
         if done < n_ops:
             tp.run(done, n_ops)
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and self.opt.account_comm:
             self._bwd_done_event = torch.cuda.Event(enable_timing=True)      # (tests: every bucket but the last went out before this)
             self._bwd_done_event.record()
 

@@ -400,5 +400,24 @@ def test_install_fused_sampler_hook_on_a_reference_style_wrapper(M):
         torch.manual_seed(5)
         img1, _ = wrapper.sample(batch)
         assert pipe.cfg.cfg_scale == 1.0 and not torch.equal(img1, img)
+        # the wrapper's ray-encoding switches are read too (diffusion_wrapper.py:301-320): Pluecker origins keep the channel count, so a
+        # hook that ignored `use_plucker` would sample silently different images than the reference wrapper
+        from mv_ldm_amd.pipeline import RayEncodingCfg
+        wrapper.model_cfg.use_plucker = True
+        torch.manual_seed(5)
+        img_p, _ = wrapper.sample(batch)
+        ref_p = MVLDMPipeline(den, vae, sch, SamplerCfg(True, 1.0, 4), rays=RayEncodingCfg(use_plucker=True))
+        torch.manual_seed(5)
+        want_p, _ = ref_p.sample({"context": batch["context"], "target": batch["target"]})
+        assert pipe.rays.use_plucker and torch.equal(img_p, want_p) and not torch.equal(img_p, img1)
+        wrapper.model_cfg.use_plucker = False
+        # config/main.yaml's default `use_ray_encoding: true` needs a denoiser with 4 + 1 + 6 * 15 + 6 * 15 input channels: refused loudly
+        wrapper.model_cfg.use_ray_encoding = True
+        wrapper.model_cfg.ray_encodings = SimpleNamespace(num_origin_octaves=15, num_direction_octaves=15)
+        with pytest.raises(ValueError):
+            wrapper.sample(batch)
+        with pytest.raises(ValueError):
+            install_fused_sampler(SimpleNamespace(model_cfg=wrapper.model_cfg, denoiser=den, autoencoder=vae, scheduler=sch, ema=None))
+        wrapper.model_cfg.use_ray_encoding = False
     with pytest.raises(TypeError):
         install_fused_sampler(SimpleNamespace(model_cfg=wrapper.model_cfg, denoiser=torch.nn.Linear(2, 2), autoencoder=vae, scheduler=sch, ema=None))

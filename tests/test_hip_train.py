@@ -498,6 +498,8 @@ def test_window_with_collectives_prefetch_and_repack_streams_on_a_one_rank_nccl_
             monkeypatch.setenv("MVLDM_TRAIN_REPACK_AHEAD", "1" if collective else "0")
             tr = build_trainer(g, torch.bfloat16, optimizer_cfg=OptimizerCfg(lr=1e-3), bucket_bytes=2 << 20,
                                group=dist.group.WORLD if collective else None, collective=collective)
+            assert tr.opt.account_comm is False           # opt-in: a production loop creates no timing events
+            tr.opt.account_comm = collective
             out = []
             for i, (bts, chs) in enumerate(seq):
                 nxt = seq[i + 1] if collective and i + 1 < len(seq) else None

@@ -29,6 +29,10 @@ def trace(sub):
         for r in csv.DictReader(open(path, newline="")):
             rows.append((short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     rows.sort(key=lambda x: x[1])
+    # bench.py --unet-pass-only brackets the pass with two `bessel_j0` launches: keep what lies between them
+    marks = [i for i, r in enumerate(rows) if "bessel_j0" in r[0]]
+    if len(marks) >= 2:
+        rows = rows[marks[0] + 1:marks[-1]]
     return rows
 
 
@@ -45,6 +49,22 @@ if rows:
         for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([n, len(v), round(sum(v) / len(v), 2), round(sum(v), 1), round(100 * sum(v) / tot, 2)])
     print(f"b64: {len(rows)} dispatches, {tot / 1e3:.2f} ms of kernels, {len(agg)} kernel templates")
+    # the roofline figure of the bench line, recomputed from this table alone: executed FLOPs of the implicit-GEMM family (bench.py prints
+    # `flops_per_pass`) over the summed durations of its kernels in the traced pass
+    fam = ("igemm_", "linear_p", "linear_ws", "linear_rs", "skinny_")
+    t_fam = sum(sum(v) for n, v in agg.items() if any(k in n for k in fam))
+    n_fam = sum(len(v) for n, v in agg.items() if any(k in n for k in fam))
+    chk = {"igemm_family_dispatches": n_fam, "igemm_family_total_ms": round(t_fam / 1e3, 3), "all_kernels_ms": round(tot / 1e3, 3), "dispatches": len(rows)}
+    bj = os.path.join(ROOT, "gpurun_out", f"r{RND}_bench.json")
+    if os.path.exists(bj):
+        try:
+            line = [x for x in open(bj) if x.startswith("{")][-1]
+            fl = json.loads(line)["roofline"]["flops_per_pass"]
+            chk.update(flops_per_pass=fl, achieved_tflops=round(fl / (t_fam * 1e-6) / 1e12, 1), frac_of_2500=round(fl / (t_fam * 1e-6) / 2.5e15, 4))
+        except Exception as e:      # noqa: BLE001
+            chk["bench_line"] = f"unreadable: {e}"
+    json.dump(chk, open(os.path.join(ROOT, "profiles", f"r{RND}_roofline_check.json"), "w"), indent=1)
+    print("roofline check:", chk)
 
 # ---- 2. MFMA utilisation per template
 pm = defaultdict(lambda: defaultdict(list))

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mv_ldm_amd._lib as L
-L.LIB_PATH = L.LIB_PATH.with_name("libmvldm_hip_exp_pwt.so")
+L.LIB_PATH = L.LIB_PATH.with_name("libmvldm_hip_exp_%s.so" % (sys.argv[4] if len(sys.argv) > 4 else "pwt"))
 from mv_ldm_amd import ops
 name = sys.argv[1]
 n = 9 * 64
@@ -28,3 +28,11 @@ for blk, wave in ((int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]
     d = [(b - a) & 0xFFFFFFFF for a, b in zip(t, t[1:])]
     print(f"{name} block {blk} wave {wave}: {len(t)} stamps; deltas (cycles) in stamp order [start->prewait, wait, barrier, sub3+next start | E = epilogue stamp follows the last step]")
     print(" ".join(str(v) for v in d))
+    big = [v for v in d if v > 6000]
+    print("  epilogue-sized gaps (> 6000 cycles):", big, " median step (sum of 4):", sorted(sum(d[i:i + 4]) for i in range(4, min(len(d) - 4, 60), 4))[6] if len(d) > 40 else None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.linear(x, pw, b, residual=r, epilogue=epi, tile=13, splitk=1)
+    e1.record(); torch.cuda.synchronize()
+    print(f"  {e0.elapsed_time(e1) * 100:.0f} us per launch")
