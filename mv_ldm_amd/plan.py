@@ -597,6 +597,7 @@ def _unpack_choice(v):
 # training plans' igemm ops up to 40000 rows: 530 - 537 training views/s either way, not kept.)
 _TUNE_COLD = int(os.environ.get("MVLDM_TUNE_COLD", "9216"))
 _THRASH = []
+_THRASH_FILLS = [0]        # cold-cache fills run so far (tests: the fill really ran; the buffer itself is freed after tuning)
 
 
 def _thrash(device=None):
@@ -674,6 +675,7 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
                     t_sum = 0.0
                     for _ in range(n_it):
                         _thrash(tune_dev).zero_()
+                        _THRASH_FILLS[0] += 1
                         e0.record()
                         lib.mvldm_op_run(C.byref(trial), stream)
                         e1.record()
