@@ -44,7 +44,7 @@ struct LinPWParams {
     int nt_store, touch;               // touch: L2 prefetch of the activation rows (pw_touch_a)
     float out_scale;
     unsigned a_bytes, a1_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
-    unsigned* trace; int trace_blk, trace_wave;     // EXPERIMENT (-DMVLDM_PW_TRACE, tools/pw_trace.py): s_memtime stamps of one wave
+    unsigned* trace; int trace_blk, trace_wave, trace_stagger;     // EXPERIMENT (-DMVLDM_PW_TRACE, tools/pw_trace.py): s_memtime stamps of one wave
 };
 
 #ifdef MVLDM_PW_TRACE
@@ -356,6 +356,11 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
     int ks_i = 1;                                // issue side: K-step of the newest ring step in flight
     const int kT = p.k_steps;
 
+#ifdef MVLDM_PW_TRACE
+    // (trace builds only, MVLDM_PW_STAGGER = n: workgroup lid starts (lid & 3) * n * 512 cycles late -- does a tile's epilogue get shorter
+    //  when the workgroups of an XCD do not reach it together?)
+    for (int i = 0; i < (lid & 3) * p.trace_stagger; ++i) __builtin_amdgcn_s_sleep(8);
+#endif
     // ---- prologue: steps 0 and 1 of the first tile (the whole ring), its bias slab ----
     {
         pw_offsets<TN>(p, true, cur.tm, cur.tn, wave, lane, ad);
@@ -660,12 +665,13 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     static const int kNt = knob_int("MVLDM_STREAM_STORES", 0);
     p.nt_store = kNt == 1;
     p.touch = (d.tile >> 13) & 1;                 // bit 13 of `tile`: the L2 prefetch (a tuner candidate: +4 % on some shapes, -9 % on others)
-    p.trace = nullptr; p.trace_blk = 0; p.trace_wave = 0;
+    p.trace = nullptr; p.trace_blk = 0; p.trace_wave = 0; p.trace_stagger = 0;
 #ifdef MVLDM_PW_TRACE
     if (const char* tp = getenv("MVLDM_PW_TRACE_PTR")) {
         p.trace = reinterpret_cast<unsigned*>(strtoull(tp, nullptr, 16));
         p.trace_blk = getenv("MVLDM_PW_TRACE_BLK") ? atoi(getenv("MVLDM_PW_TRACE_BLK")) : 8;
         p.trace_wave = getenv("MVLDM_PW_TRACE_WAVE") ? atoi(getenv("MVLDM_PW_TRACE_WAVE")) : 0;
+        p.trace_stagger = getenv("MVLDM_PW_STAGGER") ? atoi(getenv("MVLDM_PW_STAGGER")) : 0;
     }
 #endif
     if (kPwFake & 1) p.a_bytes = p.a1_bytes = 0;
