@@ -919,7 +919,7 @@ class DistributedOptimizer:
 
     def __init__(self, flat: FlatParams, cfg: OptimizerCfg = None, world: int = 1, rank: int = 0, group=None,
                  bucket_bytes: int = 256 << 20, max_norm: float = 0.1, update=None, sumsq=None, clip=None,
-                 collective: Optional[bool] = None, effective_batch_size: Optional[int] = None):
+                 collective: Optional[bool] = None, effective_batch_size: Optional[int] = None, gather_dtype: Optional[torch.dtype] = None):
         cfg = cfg or OptimizerCfg()
         if cfg.name != "AdamW":
             raise NotImplementedError(f"optimizer {cfg.name}: the released config trains with AdamW (baseline.yaml:63)")
@@ -947,6 +947,19 @@ class DistributedOptimizer:
         self.norm = torch.zeros(4, dtype=torch.float32, device=dev)
         self._update, self._sumsq, self._clip = update or _hip_adamw, sumsq or _hip_sumsq, clip or _hip_clip
         self._pending = []
+        # ---- 16-bit parameter gather (round 6).  What the next forward needs from the other ranks is their slice of the 16-bit weight
+        # PACKS -- a per-layer permutation of RNE_16(master) -- not their fp32 masters (ZeRO-1: a master is only ever updated by its
+        # owner).  With `gather_dtype` (the trainer passes its compute dtype when that is 16-bit) a rank rounds its updated slice to
+        # that type, all-gathers THOSE bytes (half of the fp32 gather: the exposed part of an 8-GPU step) and widens
+        # the other ranks' slices back into its fp32 buffer: RNE_16(float(RNE_16(x))) == RNE_16(x), so every pack comes out bit-identical
+        # to the one the fp32 gather gives.  Parameters the kernels read in fp32 (biases, norm affines: every <= 1-D parameter, ~0.1 %
+        # of the elements) travel exactly, as integers through one small all-reduce.  The price: a non-owner's copy of a weight
+        # master is 16-bit precise until `sync_masters()` gathers the fp32 slices (checkpoints; an EMA needs exact masters every
+        # step, so the trainer leaves the 16-bit gather off when it keeps one).  MVLDM_TRAIN_GATHER16=0 keeps the fp32 gather.
+        self.gather_dtype = gather_dtype if (self.collective and gather_dtype in (torch.bfloat16, torch.float16)
+                                             and os.environ.get("MVLDM_TRAIN_GATHER16", "1") != "0") else None
+        self.masters_exact = True
+        self._p16 = self._direct_idx = self._direct_own = None
         # communication accounting (bench.py --train prints it per rank; tests read the events): bytes handed to reduce-scatter /
         # all-gather, the device time the compute stream spends WAITING for outstanding collectives (`exposed`), and per bucket the
         # compute-stream event at which its reduce was enqueued (to check that it went out before the backward pass had finished)
@@ -1010,6 +1023,37 @@ class DistributedOptimizer:
             self._exposed = []
         return out
 
+    def _init_gather16(self):
+        flat = self.flat
+        dev = flat.flat.device
+        self._p16 = torch.zeros(flat.numel, dtype=self.gather_dtype, device=dev)
+        self._p16.copy_(flat.flat)
+        idx = [torch.arange(flat.offset[id(q)], flat.offset[id(q)] + q.numel(), dtype=torch.int64) for q in flat.params if q.ndim <= 1]
+        idx = torch.cat(idx) if idx else torch.zeros(0, dtype=torch.int64)
+        own = torch.zeros(idx.numel(), dtype=torch.int32)
+        for oa, ob in self.owned:
+            own |= ((idx >= oa) & (idx < ob)).to(torch.int32)
+        self._direct_idx, self._direct_own = idx.to(dev), own.to(dev)
+
+    def sync_masters(self):
+        """after steps with the 16-bit gather: bring every rank's fp32 copy of the OTHER ranks' weight masters back to the exact values
+        (the owners' slices, gathered in fp32 like the plain step does).  Call before anything reads the masters of the whole model --
+        a checkpoint, a state dict, an EMA switched on later.  A no-op while the masters are exact."""
+        if self.masters_exact or not self.collective:
+            return
+        import torch.distributed as dist
+        p = self.flat.flat
+        self.flat.wait_readers()
+        if dist.get_backend(self.group) == "gloo":
+            for (a, b) in self.buckets:
+                n = (b - a) // self.world
+                dist.all_gather([p[a + r * n:a + (r + 1) * n] for r in range(self.world)], p[a + self.rank * n:a + (self.rank + 1) * n].clone(),
+                                group=self.group)
+        else:
+            for (a, b), (oa, ob) in zip(self.buckets, self.owned):
+                dist.all_gather_into_tensor(p[a:b], p[oa:ob], group=self.group)
+        self.masters_exact = True
+
     def step(self):
         """clip (global norm over ALL ranks' slices) + AdamW on the owned slices + all-gather of the weights"""
         self.wait()
@@ -1030,21 +1074,35 @@ class DistributedOptimizer:
             import torch.distributed as dist
             gloo = dist.get_backend(self.group) == "gloo"
         works = []
+        g16 = self.gather_dtype is not None
+        if g16 and self._p16 is None:
+            self._init_gather16()
         for (a, b), (oa, ob) in zip(self.buckets, self.owned):
             n = ob - oa
             self._update(p[oa:ob], g[oa:ob], self.exp_avg[off:off + n], self.exp_avg_sq[off:off + n], lr, self.betas, self.eps,
                          self.weight_decay, self.step_count, self.norm)
             off += n
+            if g16:
+                self._p16[oa:ob].copy_(p[oa:ob])             # RNE to the pack type
             if self.collective and not gloo:
                 # in place (sendbuff == recvbuff + rank * sendcount), issued as soon as THIS bucket's slice is updated: RCCL's
                 # stream picks up behind the AdamW kernel just enqueued, so the gather of bucket k runs under the update of k+1
-                works.append(dist.all_gather_into_tensor(p[a:b], p[oa:ob], group=self.group, async_op=True))
-                self.bytes_gathered += (b - a) * 4
+                src = self._p16 if g16 else p
+                works.append(dist.all_gather_into_tensor(src[a:b], src[oa:ob], group=self.group, async_op=True))
+                self.bytes_gathered += (b - a) * (2 if g16 else 4)
         if self.collective and gloo:
+            src, es = (self._p16.view(torch.uint8), 2) if g16 else (p, 1)      # (gloo moves bytes: the 16-bit slices travel as uint8)
             for (a, b) in self.buckets:
                 n = (b - a) // self.world
-                dist.all_gather([p[a + r * n:a + (r + 1) * n] for r in range(self.world)], p[a + self.rank * n:a + (self.rank + 1) * n].clone(),
-                                group=self.group)
+                dist.all_gather([src[es * (a + r * n):es * (a + (r + 1) * n)] for r in range(self.world)],
+                                src[es * (a + self.rank * n):es * (a + (self.rank + 1) * n)].clone(), group=self.group)
+                self.bytes_gathered += (b - a) * (2 if g16 else 4)
+        small = None
+        if g16 and self._direct_idx.numel():
+            # the fp32-consumed parameters, exactly: every rank contributes the elements it owns, zeros elsewhere; integer sum
+            small = p.index_select(0, self._direct_idx).view(torch.int32) * self._direct_own
+            dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)
+            self.bytes_gathered += small.numel() * 4
         timed = self.account_comm and bool(works) and p.is_cuda
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -1055,6 +1113,15 @@ class DistributedOptimizer:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             self._exposed.append((e0, e1))
+        if g16:
+            for (a, b), (oa, ob) in zip(self.buckets, self.owned):     # the other ranks' slices, widened (exact: 16-bit -> fp32)
+                if oa > a:
+                    p[a:oa].copy_(self._p16[a:oa])
+                if b > ob:
+                    p[ob:b].copy_(self._p16[ob:b])
+            if small is not None:
+                p.index_copy_(0, self._direct_idx, small.view(torch.float32))
+            self.masters_exact = self.world == 1
         self.flat.bump()
         return float(total)
 
@@ -1175,8 +1242,10 @@ class MVLDMTrainer:
         for p in autoencoder.parameters():           # freeze.autoencoder = true (config/main.yaml:20)
             p.requires_grad_(False)
         self.flat = _flat_padded(denoiser, world)
+        # (the 16-bit parameter gather needs no exact replica of the other ranks' masters -- an EMA over the whole model does)
         self.opt = DistributedOptimizer(self.flat, optimizer_cfg, world, rank, group, bucket_bytes, self.cfg.gradient_clip_val,
-                                        collective=collective, effective_batch_size=effective_batch_size)
+                                        collective=collective, effective_batch_size=effective_batch_size,
+                                        gather_dtype=None if ema_decay is not None else self.dtype)
         self.plans: Dict[tuple, TrainPlan] = {}          # insertion order = least recently used first (plan_for_parts)
         self.max_plans = max(1, int(os.environ.get("MVLDM_TRAIN_MAX_PLANS", "4")))
         self.micro = 0
@@ -1318,12 +1387,22 @@ class MVLDMTrainer:
         self._stage_part(tp, 0, part)
         return tp
 
+    def sync_masters(self):
+        """multi-rank runs with the 16-bit parameter gather (DistributedOptimizer): make every rank's fp32 masters exact again -- call
+        before `denoiser.state_dict()` / a checkpoint.  (`denoiser_state_dict()` does.)"""
+        self.opt.sync_masters()
+
+    def denoiser_state_dict(self):
+        self.sync_masters()
+        return self.denoiser.state_dict()
+
     def load_denoiser_state_dict(self, state_dict, strict: bool = True):
         """`denoiser.load_state_dict` for a trainer that is alive: the flat parameter views are written in place, so a re-pack still
         reading them on the side stream is waited for first, and every recorded plan re-packs before its next run (ADVICE round 4:
         a plain `denoiser.load_state_dict` right after a window could leave mixed packs that were never redone)."""
         self.flat.wait_readers()
         out = self.denoiser.load_state_dict(state_dict, strict=strict)
+        self.opt.masters_exact = True             # (every rank has just loaded the same exact values)
         self._weights_gen += 1
         self.flat.bump()
         return out

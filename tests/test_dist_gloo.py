@@ -219,6 +219,70 @@ def test_sharded_optimizer_equals_single_process_adamw_world2():
     assert cuts == [(3, 11), (2, 12), (1, 22), (0, 31)]
 
 
+def _g16_worker(rank, world, port, q):
+    from mv_ldm_amd.train import DistributedOptimizer, OptimizerCfg, _flat_padded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for mode, gd in (("fp32", None), ("g16", torch.bfloat16)):
+        model = _toy_model()
+        model.pretrained_from = None
+        flat = _flat_padded(model, world)
+        opt = DistributedOptimizer(flat, OptimizerCfg(lr=1e-2, scheduler=None), world, rank, bucket_bytes=4096, max_norm=0.1, update=_torch_update,
+                                   sumsq=lambda g: (g.double() ** 2).sum().float().reshape(1), clip=_torch_clip, gather_dtype=gd)
+        assert (opt.gather_dtype is not None) == (gd is not None)
+        for step in range(3):
+            g = torch.Generator().manual_seed(100 * step + rank)
+            flat.grad.copy_(torch.randn(flat.numel, generator=g) * 0.01 * _grad_mask(flat))
+            for k in reversed(range(len(opt.buckets))):
+                opt.reduce_bucket(k)
+            opt.step()
+        out[mode] = flat.flat.numpy().copy()
+        if gd is not None:
+            assert not opt.masters_exact
+            out["direct"] = opt._direct_idx.numpy().copy()
+            out["owned"] = list(opt.owned)
+            out["bytes"] = opt.bytes_gathered
+            opt.sync_masters()
+            assert opt.masters_exact
+            out["synced"] = flat.flat.numpy().copy()
+        else:
+            out["bytes32"] = opt.bytes_gathered
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_16bit_parameter_gather_world2():
+    """round 6: the ranks exchange their updated slices rounded to the PACK type (half the bytes of the fp32 all-gather).  What must hold
+    on every rank: the 16-bit rounding of every parameter -- i.e. every weight pack, a permutation of it -- is bit-identical to the
+    fp32 gather's; the fp32-consumed (<= 1-D) parameters and the rank's own slices are exact; `sync_masters()` restores exact
+    masters everywhere."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_g16_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        o = got[rank]
+        ref, g16 = torch.from_numpy(o["fp32"]), torch.from_numpy(o["g16"])
+        assert torch.equal(ref.bfloat16(), g16.bfloat16())                                # the packs come out bit-identical
+        assert not torch.equal(ref, g16)                                                  # ... although the other rank's masters are 16-bit precise
+        d = torch.from_numpy(o["direct"])
+        assert d.numel() > 0 and torch.equal(ref[d], g16[d])                              # biases / norm affines: exact
+        for oa, ob in o["owned"]:
+            assert torch.equal(ref[oa:ob], g16[oa:ob])                                    # the rank's own slices: exact
+        assert torch.equal(torch.from_numpy(o["synced"]), ref)                            # sync_masters(): exact everywhere
+        assert np.array_equal(o["fp32"], got[0]["fp32"])
+        assert o["bytes"] < 0.6 * o["bytes32"]                                            # half the gathered bytes (+ the small exact exchange)
+
+
 def test_bucket_cut_points_hold_back_every_bucket_a_write_overlaps():
     """a parameter that straddles a bucket boundary, and a bucket lying wholly inside one parameter, must wait for that
     parameter's gradient write (a write is the flat range [off, off + numel), not its start offset)"""
