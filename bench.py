@@ -175,6 +175,7 @@ def train_bench(args, den, vae, dev, dtype, rank, world, dist, backend, barrier,
     from mv_ldm_amd.scheduler import DDIMScheduler
     from mv_ldm_amd.train import MVLDMTrainer
     torch.set_grad_enabled(False)
+    torch.manual_seed(1234 + rank)          # (the noise / timestep draws of training_step: the same from run to run, so two runs' losses compare)
     b = args.scenes if args.scenes != 64 else 4
     tr = MVLDMTrainer(den, vae, DDIMScheduler(clip_sample=False), dtype=dtype, world=world, rank=rank,
                       graph=os.environ.get("MVLDM_TRAIN_GRAPH", "0") == "1")      # (A/B knob: the window plan as one hipGraph)
