@@ -28,7 +28,7 @@ extern "C" {
  * MVLDM_OP_GATHER_ROWS / MVLDM_OP_ATTN_MERGE; bits 8-9 of mvldm_wgrad_desc.accumulate select the weight-gradient kernel form.  Everything of version 2 is
  * unchanged (additive).
  * 4 (round 5): + mvldm_pack_skinny and tile 15 / k_order 2 of mvldm_igemm_fwd (the skinny-M weight-streaming GEMM); additive over 3.
- * 5 (round 6): + tile 19 of mvldm_igemm_fwd (register-staged Linear), tile 13's bit 13, mvldm_build_flags; additive over 4. */
+ * 5 (round 6): + tile 19 of mvldm_igemm_fwd (register-staged Linear), tile 13's bits 13 / 14, mvldm_build_flags; additive over 4. */
 #define MVLDM_ABI_VERSION 5
 
 typedef void* mvldm_stream_t; /* hipStream_t */
@@ -99,7 +99,9 @@ typedef struct mvldm_igemm_desc {
                                 pack of mvldm_pack_skinny (k_order must be 2), whole K per workgroup, no split-K slab and no reduce launch;
                                 1x1 / 3x3 (stride 1 or 2) / 2x2 phase convs, one or two sources, channels in multiples of 64, every
                                 epilogue; bits 8-13 = its configuration (0 = rule; a configuration that does not fit is an error).
-                           Bits 0-5 = the tile id; bits 8-11 / 12 = tuning overrides (XCD grid, register-prefetch loop) */
+                           Bits 0-5 = the tile id; bits 8-11 / 12 = tuning overrides (XCD grid, register-prefetch loop); tile 13 only:
+                           bit 13 = L2 prefetch of the activation rows, bit 14 = issue a K-step's LDS-DMA pieces in one burst behind its
+                           barrier (the form before round 6; the default spreads them over three sub-steps -- same values, A/B) */
     int32_t k_order;    /* K order of the packed weight: 0 = (tap, channel); 1 = (64-channel block, tap, channel); 2 = the k_order-1
                            sequence in MFMA-fragment order (mvldm_pack_skinny; tile 15 only) */
     int32_t dst_ld;     /* row stride of dst in elements; 0 = n_dst (dense).  > n_dst writes into a wider buffer */

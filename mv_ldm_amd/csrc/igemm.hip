@@ -574,7 +574,8 @@ template <int TAPS, int A_IT, bool DUAL, bool UPS> struct BlAddr {
 // issue K-tile (channel block cb, tap t) into the ring slot at `stage_base`
 // (STAGES is carried only to give every kernel instantiation its own copy: sharing one specialization
 //  between two kernels trips the host pass of hipcc 7.2)
-template <typename T, int BM, int BN, int NW, int KS, bool DUAL, int A_IT, int B_IT, int STAGES, bool UPS, int t>
+// (LO, HI: the pieces [LO, HI) of the tile's A_IT + B_IT, activation pieces first -- the spread issue of the main loops)
+template <typename T, int BM, int BN, int NW, int KS, bool DUAL, int A_IT, int B_IT, int STAGES, bool UPS, int t, int LO = 0, int HI = 1 << 20>
 __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base, int wave, int cb,
                                          const BlAddr<KS * KS, A_IT, DUAL, UPS>& ad, const unsigned (&vb)[B_IT]) {
     constexpr int BK = 64, TAPS = KS * KS;
@@ -593,7 +594,7 @@ __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base,
     const bool from0 = !DUAL || c < p.c0;
     const int soff = ((from0 ? c : c - p.c0) + disp * (from0 ? p.c0 : p.c1)) * 2;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
+    for (int it = (LO > 0 ? LO : 0); it < (HI < A_IT ? HI : A_IT); ++it) {
         __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(at + (wave + NW * it) * 1024);
         unsigned v0, v1;
         if constexpr (UPS) {
@@ -609,7 +610,7 @@ __device__ __forceinline__ void bl_issue(const IgemmParams& p, char* stage_base,
     }
     const int koff = (cb * TAPS + t) * (BK * 2);
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it)
+    for (int it = (LO > A_IT ? LO - A_IT : 0); it < (HI - A_IT < B_IT ? HI - A_IT : B_IT); ++it)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(bt + (wave + NW * it) * 1024), 16,
                                                  vb[it], koff, 0, 0);
 }
@@ -751,6 +752,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     //  host pass drop the kernel's stub -- free function templates instead)
 #define MVLDM_BL_ISSUE(stage_, cb_, t_) \
     bl_issue<T, BM, BN, NW, KS, DUAL, A_IT, B_IT, STAGES, UPS, t_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, ad, vb)
+#define MVLDM_BL_ISSUE_R(stage_, cb_, t_, lo_, hi_) \
+    bl_issue<T, BM, BN, NW, KS, DUAL, A_IT, B_IT, STAGES, UPS, t_, lo_, hi_>(p, smem + (stage_) * STAGE_BYTES, wave, cb_, ad, vb)
 #define MVLDM_BL_NEXT(t_, d_) (((t_) + (d_)) % TAPS)
 #define MVLDM_BL_LOAD(f_, slot_, kk_) bl_load<T, BM, BN, WM, WN>(smem + (slot_) * STAGE_BYTES, f_, kk_, wm, wn, hi, l31)
 #define MVLDM_BL_MMA(f_)                  \
@@ -761,6 +764,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     // T+1 .. T+STAGES-1 are in the ring.  After the last fragments of tile T are read, every wave waits for
     // its pieces of tile T+1, the barrier publishes them and retires slot_c, which is refilled with tile
     // T+STAGES at once; the kk=0 fragments of tile T+1 are then fetched under tile T's last MFMAs.
+    // (round 6: the spread issue of MVLDM_BL_STEP_SIMPLE below was built here too -- 4/9 of the pieces behind the barrier, the rest in front of sub-steps
+    //  1 and 2 of the next step -- and is neutral in the step's op table: up1 / down2 +1 ... +1.5 %, up2 / down1 -1 ... -1.5 %; not kept)
 #define MVLDM_BL_STEP(t_)                                                                                         \
     {                                                                                                             \
         static_assert(64 / M_::KI == 4, "four k-sub-steps per K-tile");                                          \
@@ -785,15 +790,49 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
         MVLDM_BL_MMA(f1)                                                                                          \
     }
     // 4-wave tiles: 2-slot ring, one barrier per tile, fragments fetched right before use
+    // (round 6, SPREAD ISSUE: the next tile's LPT pieces used to go out in one burst behind the barrier -- every wave of the CU in the address path at
+    //  once, ~ 70 cycles per piece with the matrix pipe idle (the same finding as tile 13's).  Now 4/9 of the pieces go out behind the
+    //  barrier and the rest in front of sub-steps 1 and 2 (in front of their fragment reads: with the fragments live next to the piece offsets the
+    //  256 x 320 3x3 kernel spilled); the last piece still has two sub-steps of MFMAs in front of the wait that needs it.  8-wave tiles only (tile 10: the 256 x 320
+    //  convs of the 32 x 32 level, -3 % in the step's op table).  -DMVLDM_BL_BURST: the old order, A/B.)
+#ifdef MVLDM_BL_BURST
+    constexpr bool SPREAD_S = false;
+#else
+    constexpr bool SPREAD_S = NW == 8;      // (the 4-wave tiles run 2 - 4 workgroups per CU whose bursts already interleave: left as they were)
+#endif
 #define MVLDM_BL_STEP_SIMPLE(t_)                                                                                  \
     {                                                                                                             \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
         __builtin_amdgcn_s_barrier();                                                                             \
-        {                                                                                                         \
+        if constexpr (!SPREAD_S) {                                                                                \
             const int cbn_ = cb + ((t_) + 1) / TAPS;                                                              \
             if (cbn_ < cb1) { MVLDM_BL_ISSUE(slot_c ^ 1, cbn_, MVLDM_BL_NEXT(t_, 1)); }                           \
+            bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                     \
+        } else {                                                                                                  \
+            constexpr int Q0_ = (4 * LPT + 8) / 9, Q1_ = Q0_ + (LPT - Q0_ + 1) / 2;                              \
+            const int cbn_ = cb + ((t_) + 1) / TAPS;                                                              \
+            const bool more_ = cbn_ < cb1;                                                                        \
+            if (more_) { MVLDM_BL_ISSUE_R(slot_c ^ 1, cbn_, MVLDM_BL_NEXT(t_, 1), 0, Q0_); }                      \
+            {                                                                                                     \
+                BlFrags<T, TM, TN> fs_;                                                                           \
+                MVLDM_BL_LOAD(fs_, slot_c, 0);                                                                    \
+                bl_mma<T, TM, TN>(fs_, acc);                                                                      \
+            }                                                                                                     \
+            if (more_) { MVLDM_BL_ISSUE_R(slot_c ^ 1, cbn_, MVLDM_BL_NEXT(t_, 1), Q0_, Q1_); }                    \
+            {                                                                                                     \
+                BlFrags<T, TM, TN> fs_;                                                                           \
+                MVLDM_BL_LOAD(fs_, slot_c, 1);                                                                    \
+                bl_mma<T, TM, TN>(fs_, acc);                                                                      \
+            }                                                                                                     \
+            if (more_) { MVLDM_BL_ISSUE_R(slot_c ^ 1, cbn_, MVLDM_BL_NEXT(t_, 1), Q1_, LPT); }                    \
+            {                                                                                                     \
+                BlFrags<T, TM, TN> fs_;                                                                           \
+                MVLDM_BL_LOAD(fs_, slot_c, 2);                                                                    \
+                bl_mma<T, TM, TN>(fs_, acc);                                                                      \
+                MVLDM_BL_LOAD(fs_, slot_c, 3);                                                                    \
+                bl_mma<T, TM, TN>(fs_, acc);                                                                      \
+            }                                                                                                     \
         }                                                                                                         \
-        bl_compute<T, BM, BN, WM, WN>(smem + slot_c * STAGE_BYTES, acc, wm, wn, hi, l31);                         \
         slot_c ^= 1;                                                                                              \
     }
     // Deep ring (STAGES >= 4, the small-launch tiles 16 - 18): tiles t+1 .. t+STAGES-1 are in flight while tile t is consumed.  With a
@@ -879,6 +918,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
 #undef MVLDM_BL_NEXT
 #undef MVLDM_BL_STEP
 #undef MVLDM_BL_ISSUE
+#undef MVLDM_BL_ISSUE_R
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (TM * TN > 4) {
         // (the per-element fallback does not unroll at 8 accumulator blocks and would push them to scratch:

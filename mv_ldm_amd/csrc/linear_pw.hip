@@ -42,6 +42,7 @@ struct LinPWParams {
     int tiles_m, tiles_n, m_per;       // m_per: 256-row blocks per XCD
     int gm, gn, nbn, wgx;              // an XCD's wgx workgroups walk its tiles in gm x gn blocks, column chunks (nbn of them) fastest
     int nt_store, touch;               // touch: L2 prefetch of the activation rows (pw_touch_a)
+    int spread;                        // the pieces of a middle step are issued in three groups over three sub-steps (PW_STEP)
     float out_scale;
     unsigned a_bytes, a1_bytes, w_bytes, bias_bytes, res_bytes, dst_bytes;
     unsigned* trace; int trace_blk, trace_wave, trace_stagger;     // EXPERIMENT (-DMVLDM_PW_TRACE, tools/pw_trace.py): s_memtime stamps of one wave
@@ -68,6 +69,11 @@ static constexpr int kPwFake = 0;
 constexpr unsigned kPwOob = 0xFFFFFFF0u;
 constexpr unsigned kPwRowNone = 0xFFFFFFFFu;
 constexpr int PW_BM = 256, PW_NW = 8;
+#ifndef PW_SP3
+#define PW_SP3 4      // placement of a middle step's pieces (PwGeo::Q*; experiment builds override it: tools/pw_spread.sh, profiles/r06_pw_spread_variants.txt)
+#define PW_SP0 3
+#define PW_SP1 2
+#endif
 
 template <int TN> struct PwGeo {
     static constexpr int BN = 64 * TN;                  // 2 column waves of TN 32-column blocks
@@ -75,6 +81,8 @@ template <int TN> struct PwGeo {
     static constexpr int A_IT = PW_BM / 8 / PW_NW;      // 1 KiB DMA pieces (8 rows of 128 bytes) per wave: activation rows
     static constexpr int W_IT = BN / 8 / PW_NW;         // ... weight rows (= TN)
     static constexpr int P = A_IT + W_IT;               // DMA instructions per wave and step
+    // `spread`: pieces [0, Q0) go out behind the barrier (sub-step 3), [Q0, Q1) / [Q1, Q2) / [Q2, P) in sub-steps 0 / 1 / 2 of the next step
+    static constexpr int Q0 = PW_SP3 < P ? PW_SP3 : P, Q1 = Q0 + PW_SP0 < P ? Q0 + PW_SP0 : P, Q2 = Q1 + PW_SP1 < P ? Q1 + PW_SP1 : P;
     static constexpr int RING = 2 * STAGE;
     static constexpr int SLAB = RING;                   // bias of the tile's BN packed columns
     static constexpr int SMEM = SLAB + 2048;
@@ -112,7 +120,7 @@ struct PwAddr {
 // (buffer descriptors only in free functions: an opaque __amdgpu_buffer_rsrc_t inside a lambda trips hipcc's host pass)
 // The DMA pieces of a step are issued in two groups (activation rows, weight rows) so that the main loop can place each between
 // MFMAs: issued back to back at the top of a step they held BOTH waves of a SIMD in the address path while its matrix pipe idled.
-template <int TN>
+template <int TN, int LO = 0, int HI = 1 << 20>
 __device__ __forceinline__ void pw_issue_a(const LinPWParams& p, char* smem, int slot, int wave, int lane, int ks, const PwAddr& ad) {
     using G = PwGeo<TN>;
     const bool second = ks >= p.kt0;
@@ -126,25 +134,33 @@ __device__ __forceinline__ void pw_issue_a(const LinPWParams& p, char* smem, int
     const unsigned v = second ? ad.a1 : ad.a0;
     const int row = wave * 8 + (lane >> 3);
 #pragma unroll
-    for (int it = 0; it < G::A_IT; ++it) {
+    for (int it = (LO > 0 ? LO : 0); it < (HI < G::A_IT ? HI : G::A_IT); ++it) {
         const unsigned off = (ad.valid && ad.m0 + row + 64 * it < p.M) ? v : kPwOob;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(stage + (wave + PW_NW * it) * 1024), 16, off,
                                                  soff + it * 128 * c, 0, 0);
     }
 }
-template <int TN>
+template <int TN, int LO = 0, int HI = 1 << 20>
 __device__ __forceinline__ void pw_issue_w(const LinPWParams& p, char* smem, int slot, int wave, int ks, const PwAddr& ad) {
     using G = PwGeo<TN>;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
     const int soff = ks * 128;
     char* stage = smem + slot * G::STAGE + G::A_SLOT;
 #pragma unroll
-    for (int it = 0; it < G::W_IT; ++it) {
+    for (int it = (LO > 0 ? LO : 0); it < (HI < G::W_IT ? HI : G::W_IT); ++it) {
         // (n_pad is a multiple of 64 = the row stride of the pieces: a piece is inside the packed weight or outside as a whole)
         const unsigned off = (ad.valid && ad.n0 + 64 * it < p.n_pad) ? ad.w : kPwOob;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(stage + (wave + PW_NW * it) * 1024), 16, off,
                                                  soff + it * 128 * p.K, 0, 0);
     }
+}
+
+// pieces [LO, HI) of a step's P = A_IT + W_IT (activation pieces first)
+template <int TN, int LO, int HI>
+__device__ __forceinline__ void pw_issue_group(const LinPWParams& p, char* smem, int slot, int wave, int lane, int ks, const PwAddr& ad) {
+    using G = PwGeo<TN>;
+    if constexpr (LO < HI && LO < G::A_IT) pw_issue_a<TN, LO, HI>(p, smem, slot, wave, lane, ks, ad);
+    if constexpr (LO < HI && HI > G::A_IT) pw_issue_w<TN, LO - G::A_IT, HI - G::A_IT>(p, smem, slot, wave, ks, ad);
 }
 
 // L2 PREFETCH of the activation rows of a K-step a few steps ahead of the ring (round 6).  The ring lives in LDS: a step's pieces are
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
 // spilled).  In front of sub-step 3 every fragment of step g is in registers: the wave waits for step g+1's pieces (WAIT_) and its own
 // LDS reads, the barrier publishes step g+1 and RETIRES step g's slot, and sub-step 3 refills it at once with the pieces of step g+2
 // (activation rows after column 0, weight rows after column 2) while it fetches the kk = 0 fragments of step g+1 under its MFMAs.
-#define PW_SUB(ca_, cw_, na_, nw_, NEXT_, nslot_, nkk_, DMA_)                                                     \
+#define PW_SUB(ca_, cw_, na_, nw_, NEXT_, nslot_, nkk_, MODE_, SPN_)                                              \
     {                                                                                                             \
         const char* st_ = smem + (nslot_) * G::STAGE;                                                             \
         const int ao_ = a_off ^ ((nkk_) << 5), wo_ = w_off ^ ((nkk_) << 5);                                       \
@@ -399,19 +415,31 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
             acc[0][j] = PwMma<T>::mma(cw_[j], ca_[0], acc[0][j]);                                                 \
             acc[1][j] = PwMma<T>::mma(cw_[j], ca_[1], acc[1][j]);                                                 \
             if (NEXT_ && j + 1 < TN) nw_[j + 1] = pw_frag<T>(st_ + wo_ + (j + 1) * 4096);                         \
-            if (DMA_ && j == 0) {                                                                                 \
+            if ((MODE_) == 1 && j == 0) {                                                                         \
                 if (++ks_i == kT) {                                                                               \
                     ks_i = 0;                                                                                     \
                     iss.set(p, iss.r + 1, lid, m_lo, m_cnt);                                                  \
                     pw_offsets<TN>(p, iss.valid, iss.tm, iss.tn, wave, lane, ad);                                 \
                 }                                                                                                 \
-                pw_issue_a<TN>(p, smem, rs, wave, lane, ks_i, ad);                                                \
+                if (SPN_) pw_issue_group<TN, 0, G::Q0>(p, smem, rs, wave, lane, ks_i, ad);                        \
+                else pw_issue_a<TN>(p, smem, rs, wave, lane, ks_i, ad);                                           \
             }                                                                                                     \
-            if (DMA_ && j == 2) pw_issue_w<TN>(p, smem, rs, wave, ks_i, ad);                                      \
+            if ((MODE_) == 1 && j == 2 && !(SPN_)) pw_issue_w<TN>(p, smem, rs, wave, ks_i, ad);                   \
+            if ((MODE_) == 2 && j == 1 && pend) pw_issue_group<TN, G::Q0, G::Q1>(p, smem, rs ^ 1, wave, lane, ks_i, ad); \
+            if ((MODE_) == 3 && j == 1 && pend) pw_issue_group<TN, G::Q1, G::Q2>(p, smem, rs ^ 1, wave, lane, ks_i, ad); \
+            if ((MODE_) == 4 && j == 1 && pend) pw_issue_group<TN, G::Q2, G::P>(p, smem, rs ^ 1, wave, lane, ks_i, ad);  \
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     }
-#define PW_STEP(LAST_, WAIT_, TOUCH_)                                                                             \
+// SPREAD ISSUE (round 6; tile bit 14 switches it off for A/B).  The P = 8 / 9 pieces a wave requests per step (step g+2's, into the slot the
+// barrier of step g has just retired) used to go out in one burst behind that barrier: 8 waves x P LDS-DMA instructions at once, each holding
+// its wave in the address path for 70 - 75 cycles while the matrix pipe waited (the vendor GEMM pays ~ 50 per piece).  Now 4 go
+// out behind the barrier and 3 + 2 in sub-steps 0 and 1 of the NEXT step (`pend`); the wait in front of that step's barrier is still vmcnt(0) and
+// still covers them, the results are bit-identical.  -4 ... -10 % on the residual Linears, -1 ... -6 % on the QKV projections, GEGLU unchanged
+// (profiles/r06_pw_spread_variants.txt: placements 3-3-3 ... 6-1-2 and 0-3-3, which is slower than the burst).  Only between two steps that both
+// have those sub-steps free: the last two steps of a tile (next tile's steps 0 / 1, waited for round the epilogue's own loads and stores) keep the
+// burst, and so does the touch variant (its vmcnt(1) needs the touch to be the step's youngest VMEM instruction).
+#define PW_STEP(LAST_, WAIT_, TOUCH_, SPN_)                                                                       \
     {                                                                                                             \
         PW_STAMP()                                                                                                \
         if ((TOUCH_) && p.touch) {                                                                                \
@@ -421,18 +449,24 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
             pw_touch_a<TN>(p, smem, wave, lane, __builtin_amdgcn_readfirstlane(own_ ? cur.tm : nxt.tm),           \
                            __builtin_amdgcn_readfirstlane(own_ ? kt_ : kt_ - kT), own_ || nxt.valid);             \
         }                                                                                                         \
-        PW_SUB(fa0, fw0, fa1, fw1, true, rs, 1, false)                                                            \
-        PW_SUB(fa1, fw1, fa0, fw0, true, rs, 2, false)                                                            \
-        PW_SUB(fa0, fw0, fa1, fw1, true, rs, 3, false)                                                            \
+        PW_SUB(fa0, fw0, fa1, fw1, true, rs, 1, 2, false)                                                         \
+        PW_SUB(fa1, fw1, fa0, fw0, true, rs, 2, 3, false)                                                         \
+        PW_SUB(fa0, fw0, fa1, fw1, true, rs, 3, 4, false)                                                         \
         PW_STAMP()                                                                                                \
         if ((TOUCH_) && p.touch) __builtin_amdgcn_s_waitcnt(kWaitStep1);                                          \
         else __builtin_amdgcn_s_waitcnt(WAIT_);                                                                   \
         PW_STAMP()                                                                                                \
         __builtin_amdgcn_s_barrier();                                                                             \
         PW_STAMP()                                                                                                \
-        PW_SUB(fa1, fw1, fa0, fw0, !(LAST_), rs ^ 1, 0, true)                                                     \
+        {                                                                                                         \
+            const bool spn_ = (SPN_);                                                                             \
+            PW_SUB(fa1, fw1, fa0, fw0, !(LAST_), rs ^ 1, 0, 1, spn_)                                              \
+            pend = spn_;                                                                                          \
+        }                                                                                                         \
         rs ^= 1;                                                                                                  \
     }
+    bool pend = false;                                           // groups 2 and 3 of the newest step's pieces are still to be issued
+    const bool sp = p.spread && !p.touch && kT >= 4;
     Frag fa0[2], fw0[TN], fa1[2], fw1[TN];
     constexpr int kWaitLds = 0xC07F;                             // lgkmcnt(0) only
     constexpr int kWaitFirst = pw_wait(4 * NOUT) & ~0x0F00;      // step 1 of the tile has landed: everything but the previous epilogue's 4 * NOUT stores
@@ -462,10 +496,10 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) fw0[j] = pw_frag<T>(st0 + w_off + j * 4096);
         }
-        { const int ks_t = 0; PW_STEP(false, kWaitFirst, false) }
+        { const int ks_t = 0; PW_STEP(false, kWaitFirst, false, sp) }
         // (the middle steps carry one touch each: issued at the top of the step, i.e. younger than the pieces the step waits for)
 #pragma unroll 1
-        for (int ks_t = 1; ks_t < kT - 1; ++ks_t) PW_STEP(false, kWaitStepT, true)
+        for (int ks_t = 1; ks_t < kT - 1; ++ks_t) PW_STEP(false, kWaitStepT, true, sp && ks_t + 2 < kT)
         // Last step: nothing of the next tile is read before the epilogue.  The next tile's bias is requested here (inline asm: consumed
         // in the epilogue behind a counted wait that leaves the ring pieces this step issues in flight -- the epilogue does not drain the ring)
         u32x4 bnext;
@@ -475,7 +509,7 @@ __global__ __launch_bounds__(512) void linear_pw_kernel(const LinPWParams p) {
             const unsigned boff = pw_bias_off<TN>(p, GEGLU, nxt.valid, nxt.tn, tid);
             asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(bnext) : "v"(boff), "s"(rbias));
         }
-        { const int ks_t = 0; PW_STEP(true, kWaitLds, false) }
+        { const int ks_t = 0; PW_STEP(true, kWaitLds, false, false) }
         // ---- epilogue: straight from the accumulators (header) ----
         PW_STAMP()
         {
@@ -664,6 +698,7 @@ int linear_pw_run(const mvldm_igemm_desc& d, hipStream_t s) {
     // write-back stores unless forced (header): MVLDM_STREAM_STORES=1 is the A/B knob
     static const int kNt = knob_int("MVLDM_STREAM_STORES", 0);
     p.nt_store = kNt == 1;
+    p.spread = !((d.tile >> 14) & 1);             // bit 14 of `tile` = A/B: issue every step's pieces in one burst behind its barrier (the round-4/5 form)
     p.touch = (d.tile >> 13) & 1;                 // bit 13 of `tile`: the L2 prefetch (a tuner candidate: +4 % on some shapes, -9 % on others)
     p.trace = nullptr; p.trace_blk = 0; p.trace_wave = 0; p.trace_stagger = 0;
 #ifdef MVLDM_PW_TRACE

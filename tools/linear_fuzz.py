@@ -11,7 +11,7 @@ from mv_ldm_amd import ops, _lib as L
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 torch.manual_seed(1)
-TILES = (13, 13 | (1 << 13), 19)
+TILES = (13, 13, 13 | (1 << 13), 13 | (1 << 14), 19)        # 13: spread issue (default), bit 13: + L2 touch, bit 14: burst issue (A/B)
 bad = refused = ran = 0
 worst = 0.0
 for ci in range(cases):

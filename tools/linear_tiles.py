@@ -45,7 +45,8 @@ for name, rows, k, nn, epi, res in SH:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
-        rec[f"t{tile}"] = [round(us), round(2.0 * rows * k * nn / us / 1e6)]
+        if f"t{tile}" not in rec or us < rec[f"t{tile}"][0]:          # (a tile listed twice: the faster sample -- the first one of a shape meets a colder clock)
+            rec[f"t{tile}"] = [round(us), round(2.0 * rows * k * nn / us / 1e6)]
     if "--blas" in sys.argv:
         # yardstick: the vendor GEMM (hipBLASLt through torch) on the same operands.  Plain GEMM + bias only -- no GEGLU product, no residual
         # add: its number is what the library needs for LESS work than the fused launch above does.
