@@ -797,8 +797,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_bl_kernel(const IgemmParams
     //  convs of the 32 x 32 level, -3 % in the step's op table).  -DMVLDM_BL_BURST: the old order, A/B.)
 #ifdef MVLDM_BL_BURST
     constexpr bool SPREAD_S = false;
+#elif defined(MVLDM_BL_SPREAD_ALL)
+    constexpr bool SPREAD_S = true;         // (experiment: the 4-wave tiles too)
 #else
-    constexpr bool SPREAD_S = NW == 8;      // (the 4-wave tiles run 2 - 4 workgroups per CU whose bursts already interleave: left as they were)
+    constexpr bool SPREAD_S = NW == 8;      // (the 4-wave tiles run 2 - 4 workgroups per CU whose bursts already interleave: with it, -DMVLDM_BL_SPREAD_ALL, the 1 / 4-scene steps are 0.6 - 1 % slower)
 #endif
 #define MVLDM_BL_STEP_SIMPLE(t_)                                                                                  \
     {                                                                                                             \
