@@ -61,4 +61,21 @@ for name, rows, k, nn, epi, res in SH:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         rec["hipblaslt_gemm_bias_only"] = [round(us), round(2.0 * rows * k * nn / us / 1e6)]
+        if res or epi == 2:
+            # the SAME op as the fused launch, the vendor way: its GEMM + bias, then the elementwise kernel(s) torch needs for the residual add / the
+            # GEGLU product (in place where torch allows it)
+            if res:
+                g = lambda: torch.nn.functional.linear(x, wt, b.to(dtype)).add_(r)
+            else:
+                def g():
+                    y = torch.nn.functional.linear(x, wt, b.to(dtype))
+                    return y[:, :nn // 2] * torch.nn.functional.gelu(y[:, nn // 2:])
+            g(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                g()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 100
+            rec["hipblaslt_plus_eltwise_same_op"] = [round(us), round(2.0 * rows * k * nn / us / 1e6)]
     print(json.dumps(rec), flush=True)
