@@ -16,6 +16,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import sys
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -475,6 +476,8 @@ class Builder:
         if autotune and torch.device(self.device).type == "cuda":
             autotune_igemm(self.ops, srcs=self.__dict__.get("_tune_srcs"), skinny=self._skinny_pw, keep=self.keep)
             autotune_wgrad(self.ops)
+            if type(self) is Builder and _BATCH_SPLIT:      # (training plans address their ops by index: grad_writes, collective segments)
+                self.ops, self.meta = autosplit_igemm(self.ops, self.meta, skinny=self._skinny_pw, keep=self.keep)
         return Plan(self.ops, self.meta, self.keep, self.device)
 
 
@@ -487,6 +490,7 @@ class Builder:
 # MVLDM_TUNE_TILES=0,2,9,... restricts the candidates (the small 64x64 / 32x64 tiles only ever win below ~4 scenes: +2 % at b = 1).
 _TUNE_CACHE = {}
 _WGRAD_CACHE = {}
+_SPLIT_CACHE = {}         # igemm problem signature -> images of part A of a batch split (0 = keep the launch whole): autosplit_igemm
 _VALIDATED = set()         # igemm cache entries this process has launched once (entries loaded from a file are trial-launched before use)
 _TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) if os.environ.get("MVLDM_TUNE_TILES") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)
 
@@ -497,14 +501,16 @@ _TUNE_TILES = tuple(int(t) for t in os.environ["MVLDM_TUNE_TILES"].split(",")) i
 # second process records its plans WITHOUT a single trial launch; `broadcast_tune_cache` gives the ranks of a job rank 0's choices.
 def tune_cache_state() -> dict:
     return {"version": 2, "igemm": {json.dumps(list(k)): (int(v) if isinstance(v, int) else list(v)) for k, v in _TUNE_CACHE.items()},
-            "wgrad": {json.dumps(list(k)): int(v) for k, v in _WGRAD_CACHE.items()}}
+            "wgrad": {json.dumps(list(k)): int(v) for k, v in _WGRAD_CACHE.items()},
+            "split": {json.dumps(list(k)): int(v) for k, v in _SPLIT_CACHE.items()}}
 
 
 def set_tune_cache_state(state: dict, replace: bool = False) -> None:
     if replace:
         _TUNE_CACHE.clear()
         _WGRAD_CACHE.clear()
-    for name, cache in (("igemm", _TUNE_CACHE), ("wgrad", _WGRAD_CACHE)):
+        _SPLIT_CACHE.clear()
+    for name, cache in (("igemm", _TUNE_CACHE), ("wgrad", _WGRAD_CACHE), ("split", _SPLIT_CACHE)):
         for k, v in (state.get(name) or {}).items():
             cache[tuple(json.loads(k))] = int(v) if isinstance(v, int) else list(v)
 
@@ -526,7 +532,7 @@ def load_tune_cache(path: Optional[str] = None) -> int:
         return 0
     with open(path) as f:
         set_tune_cache_state(json.load(f))
-    return len(_TUNE_CACHE) + len(_WGRAD_CACHE)
+    return len(_TUNE_CACHE) + len(_WGRAD_CACHE) + len(_SPLIT_CACHE)
 
 
 def broadcast_tune_cache(dist, src: int = 0, device=None) -> None:
@@ -729,6 +735,122 @@ def autotune_igemm(ops, min_rows: int = 2048, iters: int = 4, srcs=None, skinny=
         save_tune_cache()
         _THRASH.clear()                      # the 640 MB cold-cache fill is a tuning-time buffer: not kept past the plan that needed it
     return timed
+
+
+# ---- batch split of the big implicit-GEMM launches (round 6) ---------------------------------------------------------------
+# A launch of T tiles on 256 CUs takes ceil(T / 256) rounds: the 16x16-level convs of the headline (640 tiles of 256 x 320) pay 3 rounds for 2.5,
+# the 8x8-level ones 2 for 1.25 -- and a smaller tile for the WHOLE launch trades that for arithmetic intensity (256 x 128: 85 flop per L2->LDS
+# byte instead of 142).  The images of a batch are independent rows of the GEMM: the launch is cut at an image boundary into a part whose big
+# tiles fill whole rounds and a remainder that is tuned on its own (smaller tiles and / or a K split: `autotune_igemm` times every tile x split
+# for launches below MVLDM_TUNE_MID_ROWS) -- the cheap half of what a stream-K GEMM does with its ragged last round.  Decided by timing, per problem
+# signature, like the tiles: both parts are tuned, then [whole] is timed against [part A, part B]; the split is kept if it is > 3 % faster.
+# Sampling plans only; MVLDM_BATCH_SPLIT=0 keeps every launch whole (A/B).  The values of a split launch differ from the whole launch's only
+# through the remainder's tile / K-split (last-bit rounding, like any other tuner choice).
+_BATCH_SPLIT = os.environ.get("MVLDM_BATCH_SPLIT", "1") != "0"
+_SPLIT_MIN_ROWS = int(os.environ.get("MVLDM_BATCH_SPLIT_MIN_ROWS", "16384"))
+
+
+def _split_candidates(d) -> list:
+    """image counts n1 (0 < n1 < n_img) at which part A = whole rounds of 256 x BN tiles for a BN the big tiles offer"""
+    rpi = d.h_out * d.w_out
+    rows = d.n_img * rpi
+    out = []
+    for bn in (320, 256):
+        n_tiles = -(-d.n_pad // bn)
+        m_tiles = -(-rows // 256)
+        if m_tiles * n_tiles <= 256 or (m_tiles * n_tiles) % 256 == 0 or (m_tiles * n_tiles) % 256 > 216:
+            continue                                  # one round, or a last round that is (nearly) full already
+        for m1 in range(m_tiles - 1, 0, -1):          # the largest whole-round prefix that ends on an image boundary
+            if (m1 * n_tiles) % 256 == 0 and (m1 * 256) % rpi == 0:
+                n1 = m1 * 256 // rpi
+                frac = 1.0 - n1 / d.n_img
+                if 0.03 <= frac <= 0.45 and n1 not in out:
+                    out.append(n1)
+                break
+    return out
+
+
+def _image_range(op, i0: int, n: int):
+    """a copy of igemm op `op` restricted to images [i0, i0 + n) (NHWC tensors: a pointer offset per operand)"""
+    q = L.Op()
+    C.memmove(C.byref(q), C.byref(op), C.sizeof(L.Op))
+    d = q.u.igemm
+    es = 4 if d.act_dtype == L.F32 else 2
+    ds = 4 if d.dst_dtype == L.F32 else 2
+    n_dst = d.n_out // 2 if d.epilogue == L.EPI_GEGLU else d.n_out
+    px_in, px_out = d.h_in * d.w_in, d.h_out * d.w_out
+
+    def off(p, nbytes):
+        return (p + nbytes) if p else p
+    d.src0 = off(d.src0, i0 * px_in * d.c0 * es)
+    d.src1 = off(d.src1, i0 * px_in * d.c1 * es)
+    d.dst = off(d.dst, i0 * px_out * (d.dst_ld or n_dst) * ds)
+    d.residual = off(d.residual, i0 * px_out * n_dst * es)
+    d.row_bias = off(d.row_bias, i0 * d.row_bias_ld * 4)
+    d.n_img = n
+    d.tile, d.splitk = 0, 0
+    return q
+
+
+def _time_ops(ops, iters: int) -> float:
+    lib = L.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for o in ops:
+        L.check(lib.mvldm_op_run(C.byref(o), stream))
+    e0.record()
+    for _ in range(iters):
+        for o in ops:
+            lib.mvldm_op_run(C.byref(o), stream)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def autosplit_igemm(ops, meta, skinny=None, keep=None, iters: int = 6):
+    """cut big 16-bit igemm launches at an image boundary where two launches are faster than one (see above); returns the new (ops, meta)"""
+    new_ops, new_meta, decided = [], [], 0
+    for idx, (op, m) in enumerate(zip(ops, meta)):
+        d = op.u.igemm if op.kind == L.OP_IGEMM else None
+        rows = d.n_img * d.h_out * d.w_out if d is not None else 0
+        ok = (d is not None and rows >= _SPLIT_MIN_ROWS and d.act_dtype != L.F32 and d.k_order == 1 and d.stride == 1 and not d.upsample
+              and (d.tile & 63) != 15 and not _PIN_TILE() and bool(d.workspace) and idx not in (skinny or {}))
+        n1 = 0
+        if ok:
+            key = _igemm_signature(d)[:-2] + (d.workspace_bytes,)          # (the tuned tile / split of the whole launch are not part of the problem)
+            if key in _SPLIT_CACHE:
+                n1 = _SPLIT_CACHE[key]
+            else:
+                best_t, t_whole = None, None
+                for cand in _split_candidates(d):
+                    parts = [_image_range(op, 0, cand), _image_range(op, cand, d.n_img - cand)]
+                    autotune_igemm(parts, iters=4)
+                    if t_whole is None:
+                        t_whole = _time_ops([op], iters)
+                    t = _time_ops(parts, iters)
+                    if os.environ.get("MVLDM_BATCH_SPLIT_LOG"):
+                        print(f"[batch split] {m.name}: {d.n_img} images x {d.h_out}x{d.w_out}, N {d.n_out}, K {d.k_pad}: whole {t_whole * 1e3:.1f} us (tile {d.tile & 63}, "
+                              f"splitk {d.splitk}); {cand} + {d.n_img - cand}: {t * 1e3:.1f} us (tiles {parts[0].u.igemm.tile & 63} / {parts[1].u.igemm.tile & 63}, "
+                              f"splitk {parts[1].u.igemm.splitk})", file=sys.stderr, flush=True)
+                    if t < 0.97 * t_whole and (best_t is None or t < best_t):
+                        best_t, n1 = t, cand
+                _SPLIT_CACHE[key] = n1
+                decided += 1
+        if n1:
+            parts = [_image_range(op, 0, n1), _image_range(op, n1, d.n_img - n1)]
+            autotune_igemm(parts, iters=4)          # (from the cache: nothing is timed twice)
+            for k, (q, i0, cnt) in enumerate(zip(parts, (0, n1), (n1, d.n_img - n1))):
+                q.tag = len(new_ops)
+                new_ops.append(q)
+                share = cnt / d.n_img
+                new_meta.append(OpMeta(m.name if k == 0 else m.name + "[rest]", m.kind, m.flops * share, m.bytes * share))
+        else:
+            op.tag = len(new_ops)
+            new_ops.append(op)
+            new_meta.append(m)
+    if decided:
+        save_tune_cache()
+    return new_ops, new_meta
 
 
 _WGRAD_TARGETS = tuple(int(t) for t in os.environ.get("MVLDM_TUNE_WGRAD_TARGETS", "0,1,2,3,4,5").split(","))      # 0 = library default, 64 << code

@@ -165,7 +165,9 @@ def test_plan_time_autotune_freezes_a_valid_tile(ops):
         y2 = bld.conv(x, pw, name="probe_again")            # same problem: served from the cache
         plan = bld.finalize(autotune=tune)
         if tune:
-            assert len(P._TUNE_CACHE) == 1 and P._unpack_choice(next(iter(P._TUNE_CACHE.values())))[0] in P._TUNE_TILES      # ([tile, split-K] since round 4)
+            # (one entry for the problem itself; the parts a batch split tried -- plan.autosplit_igemm, round 6 -- have their own image counts)
+            whole = [k for k in P._TUNE_CACHE if k[0] == 36]
+            assert len(whole) == 1 and P._unpack_choice(P._TUNE_CACHE[whole[0]])[0] in P._TUNE_TILES      # ([tile, split-K] since round 4)
         plan.run()
         torch.cuda.synchronize()
         outs.append((y.clone(), y2.clone()))
@@ -213,3 +215,57 @@ def test_every_candidate_the_tuner_may_freeze_reproduces_the_rules_result(ops):
                 assert e < 6e-3, (name, tile, sk, e)
                 assert torch.equal(y, ops.conv2d(x, pw, b, tile=tile, splitk=sk, **kw)), (name, tile, sk, "second run differs")
     assert tried > 200 and refused > 0, (tried, refused)
+
+
+def test_batch_split_cuts_a_launch_at_an_image_boundary(ops, monkeypatch):
+    """plan.autosplit_igemm (round 6): a big igemm launch becomes [images 0 .. n1) + [n1 .. n) when two launches are faster.  Forced here (the timing
+    helper is patched to prefer every split): the two launches together must write what the whole launch writes -- every operand that is indexed
+    by the image (both sources, the residual, the per-image row bias, the output) gets its pointer offset -- and the decision is cached per problem."""
+    from mv_ldm_amd import _lib as L
+    from mv_ldm_amd import plan as P
+    dtype = torch.bfloat16
+    n, hw, c0, c1, co = 80, 16, 320, 192, 640
+    x = _randn((n, hw, hw, c0), 21, dtype)
+    x2 = _randn((n, hw, hw, c1), 22, dtype)
+    w = _randn((co, c0 + c1, 3, 3), 23, torch.float32, 1.0 / math.sqrt(9 * (c0 + c1)))
+    pw = ops.pack_weight(w, dtype, c_split=c0)
+    bias = _randn((co,), 24, torch.float32)
+    row_bias = _randn((n, co), 25, torch.float32)
+    res = _randn((n, hw, hw, co), 26, dtype)
+    ref = ops.conv2d(x, pw, bias, x2=x2, row_bias=row_bias, residual=res)
+    wl = _randn((co, c0), 27, torch.float32, 1.0 / math.sqrt(c0))
+    pwl = ops.pack_weight(wl, dtype)
+    xl = x.view(-1, c0)
+    ref_l = ops.linear(xl, pwl, bias, residual=res.view(-1, co))
+
+    calls = []
+    real = P._time_ops
+    monkeypatch.setattr(P, "_time_ops", lambda ops_, iters: (calls.append(len(ops_)), real(ops_, 1) * (0.5 if len(ops_) == 2 else 1.0))[1])
+    monkeypatch.setattr(P, "_split_candidates", lambda d: [d.n_img * 3 // 4 // (256 // math.gcd(256, d.h_out * d.w_out)) * (256 // math.gcd(256, d.h_out * d.w_out))])
+    monkeypatch.setattr(P, "_SPLIT_MIN_ROWS", 4096)
+    P._SPLIT_CACHE.clear()
+    bld = P.Builder(x.device, dtype, record=True)
+    y = bld.conv(x, pw, bias, x2=x2, row_bias=row_bias, residual=res, name="conv")
+    yl = bld.linear(xl, pwl, bias, residual=res.view(-1, co), name="linear")
+    y_again = bld.conv(x, pw, bias, x2=x2, row_bias=row_bias, residual=res, name="conv_again")
+    plan = bld.finalize(autotune=True)
+    names = [m.name for m in plan.meta]
+    assert names == ["conv", "conv[rest]", "linear", "linear[rest]", "conv_again", "conv_again[rest]"], names
+    assert len(P._SPLIT_CACHE) == 2 and all(v > 0 for v in P._SPLIT_CACHE.values())         # (conv_again: from the cache)
+    d0, d1 = plan.ops[0].u.igemm, plan.ops[1].u.igemm
+    assert d0.n_img + d1.n_img == n and d1.src0 - d0.src0 == d0.n_img * hw * hw * c0 * 2 and d1.src1 - d0.src1 == d0.n_img * hw * hw * c1 * 2
+    assert d1.row_bias - d0.row_bias == d0.n_img * co * 4 and d1.dst - d0.dst == d0.n_img * hw * hw * co * 2 == d1.residual - d0.residual
+    assert abs(sum(m.flops for m in plan.meta[:2]) - 2.0 * n * hw * hw * co * 9 * (c0 + c1)) < 1.0
+    for t in (y, yl, y_again):
+        t.zero_()
+    plan.run()
+    torch.cuda.synchronize()
+    for got, want in ((y, ref), (y_again, ref), (yl, ref_l)):
+        assert torch.isfinite(got.float()).all()
+        assert (got.float() - want.float()).norm() / want.float().norm() < 4e-3      # (tile / K-split of the parts: rounding only)
+    assert torch.equal(y, y_again)
+    # the kill switch keeps every launch whole
+    monkeypatch.setattr(P, "_BATCH_SPLIT", False)
+    bld = P.Builder(x.device, dtype, record=True)
+    bld.conv(x, pw, bias, x2=x2, row_bias=row_bias, residual=res, name="conv")
+    assert [m.name for m in bld.finalize(autotune=True).meta] == ["conv"]
