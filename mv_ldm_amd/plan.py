@@ -824,10 +824,13 @@ def autosplit_igemm(ops, meta, skinny=None, keep=None, iters: int = 6):
                 best_t, t_whole = None, None
                 for cand in _split_candidates(d):
                     parts = [_image_range(op, 0, cand), _image_range(op, cand, d.n_img - cand)]
-                    autotune_igemm(parts, iters=4)
-                    if t_whole is None:
-                        t_whole = _time_ops([op], iters)
-                    t = _time_ops(parts, iters)
+                    try:
+                        autotune_igemm(parts, iters=4)
+                        if t_whole is None:
+                            t_whole = _time_ops([op], iters)
+                        t = _time_ops(parts, iters)
+                    except L.MvldmError:          # a part the library refuses where it takes the whole launch: the launch stays whole
+                        continue
                     if os.environ.get("MVLDM_BATCH_SPLIT_LOG"):
                         print(f"[batch split] {m.name}: {d.n_img} images x {d.h_out}x{d.w_out}, N {d.n_out}, K {d.k_pad}: whole {t_whole * 1e3:.1f} us (tile {d.tile & 63}, "
                               f"splitk {d.splitk}); {cand} + {d.n_img - cand}: {t * 1e3:.1f} us (tiles {parts[0].u.igemm.tile & 63} / {parts[1].u.igemm.tile & 63}, "
