@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -42,6 +43,24 @@ template <bool BIG> __global__ __launch_bounds__(256) void mfma_loop(float* out,
     out[blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+
+// the same loop on f16 operands (the reference's own 16-mixed type): 10 mantissa bits in the multipliers instead of 7
+__global__ __launch_bounds__(256) void mfma_loop_f16(float* out, int iters, int zero) {
+    unsigned s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    f16x8 a[4], b[4];
+    for (int f = 0; f < 4; ++f)
+        for (int i = 0; i < 8; ++i) { a[f][i] = (_Float16)(zero ? 0.f : rnd(s)); b[f][i] = (_Float16)(zero ? 0.f : rnd(s)); }
+    f32x16 acc[16];
+    for (int j = 0; j < 16; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j & 3], b[j >> 2], acc[j], 0, 0, 0);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < 16; ++j) for (int r = 0; r < 16; ++r) sum += acc[j][r];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 2.0;
     float* out; hipMalloc(&out, 1024 * 256 * sizeof(float));
@@ -66,5 +85,18 @@ int main(int argc, char** argv) {
                 printf("%-7s %s  %d wave(s)/SIMD: first-launch-best %.0f  settled %.0f TFLOP/s  (%d launches)\n", zero ? "zeros" : "random",
                        big ? "32x32x16" : "16x16x32", wps, best, last, reps);
             }
+    for (int zero = 0; zero < 2; ++zero) {
+        const int blocks = 512, iters = 20000;
+        double last = 0, t_tot = 0;
+        while (t_tot < secs * 1e3) {
+            hipEventRecord(e0);
+            mfma_loop_f16<<<blocks, 256>>>(out, iters, zero);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            last = (double)blocks * 4 * iters * 16 * 32768.0 / ms / 1e9;
+            t_tot += ms;
+        }
+        printf("%-7s 32x32x16 f16, 2 wave(s)/SIMD: settled %.0f TFLOP/s\n", zero ? "zeros" : "random", last);
+    }
     return 0;
 }
